@@ -1,0 +1,130 @@
+"""ctypes binding of libgandanet_hip.so (C ABI: include/gandanet.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, this raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgandanet_hip.so")
+
+PREC_FP32, PREC_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY02 = 0, 1, 2
+
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("M", C.c_int), ("Mstore", C.c_int), ("Ck", C.c_int), ("ks", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("transposed", C.c_int),
+        ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("a", c_fp), ("a_bs", C.c_long), ("a_sm", C.c_long), ("a_sc", C.c_long), ("a_st", C.c_long),
+        ("x", c_fp), ("x_bs", C.c_long),
+        ("in_scale", c_fp), ("in_shift", c_fp), ("in_relu", C.c_int),
+        ("y", c_fp), ("y_bs", C.c_long),
+        ("out_layout", C.c_int), ("out_bf16", C.c_int), ("ldo", C.c_int),
+        ("alpha", c_fp), ("bias", c_fp), ("res", c_fp), ("res_bs", C.c_long),
+        ("act", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int),
+    ]
+
+
+class GemmNTDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("M", C.c_int), ("N", C.c_int), ("kseg", C.c_int), ("klen", C.c_long),
+        ("a", c_fp), ("a_bs", C.c_long), ("a_ss", C.c_long), ("lda", C.c_long),
+        ("bm", c_fp), ("b_bs", C.c_long), ("b_ss", C.c_long), ("ldb", C.c_long),
+        ("im2col", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("in_scale", c_fp), ("in_shift", c_fp), ("in_relu", C.c_int),
+        ("c", c_fp), ("c_bs", C.c_long), ("ldc", C.c_long),
+        ("alpha", c_fp), ("bias", c_fp),
+        ("accumulate", C.c_int), ("splits", C.c_int), ("precision", C.c_int),
+    ]
+
+
+_i, _l, _f, _p, _sz = C.c_int, C.c_long, C.c_float, c_fp, C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/gandanet.h
+SIGNATURES = {
+    "gd_version": (_i, []),
+    "gd_last_error": (_i, [C.c_char_p, _i]),
+    "gd_sizeof_conv_desc": (_i, []),
+    "gd_sizeof_gemm_nt_desc": (_i, []),
+    "gd_conv2d": (_i, [C.POINTER(ConvDesc), _p]),
+    "gd_gemm_nt": (_i, [C.POINTER(GemmNTDesc), _p]),
+    "gd_bn_stats_ws_floats": (_sz, [_i, _i, _l]),
+    "gd_bn_stats": (_i, [_p, _l, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "gd_bn_fold": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),
+    "gd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "gd_affine_act": (_i, [_p, _l, _p, _p, _i, _i, _l, _i, _p, _l, _p]),
+    "gd_bn_act_bwd": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p, _p, _p, _l, _i, _p, _p]),
+    "gd_bicubic_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
+    "gd_bicubic_bwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
+    "gd_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p]),
+    "gd_bilinear_bwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
+    "gd_maxpool2_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
+    "gd_maxpool2_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gd_act_fwd": (_i, [_p, _p, _l, _i, _p]),
+    "gd_act_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
+    "gd_axpby": (_i, [_p, _f, _p, _f, _l, _p]),
+    "gd_scale_dev": (_i, [_p, _p, _p, _l, _i, _p]),
+    "gd_copy_rows": (_i, [_p, _l, _l, _p, _l, _l, _i, _i, _i, _p]),
+    "gd_channel_sum": (_i, [_p, _l, _i, _i, _l, _p, _i, _p, _p]),
+    "gd_copy_slab": (_i, [_p, _l, _p, _l, _i, _l, _i, _p]),
+    "gd_softmax_rows": (_i, [_p, _p, _l, _i, _f, _p]),
+    "gd_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
+    "gd_dot": (_i, [_p, _p, _l, _p, _i, _p, _p]),
+    "gd_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
+    "gd_add_transpose": (_i, [_p, _p, _i, _i, _p]),
+    "gd_bce_logits": (_i, [_p, _l, _f, _p, _p, _p, _p]),
+    "gd_mse": (_i, [_p, _p, _l, _p, _p, _p, _p]),
+    "gd_l1": (_i, [_p, _p, _l, _p, _p, _p, _p]),
+    "gd_tv": (_i, [_p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "gd_ssim": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "gd_adamw": (_i, [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f, _p]),
+    "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
+    "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _i, _p, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class GandanetError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library (once) and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GandanetError(
+            f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gd_sizeof_conv_desc() != C.sizeof(ConvDesc) or lib.gd_sizeof_gemm_nt_desc() != C.sizeof(GemmNTDesc):
+        raise GandanetError("descriptor struct layout differs between _lib.py and libgandanet_hip.so")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().gd_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise GandanetError(f"{what or 'gandanet call'} failed (rc={rc}): {last_error()}")

@@ -1,0 +1,31 @@
+"""Run-time switches of the product path."""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from dataclasses import dataclass
+
+
+@dataclass
+class _Config:
+    # MFMA operand type of the GEMM-shaped kernels: "bf16" (v_mfma_f32_32x32x16_bf16, fused flash PAM)
+    # or "fp32" (exact v_mfma_f32_32x32x2_f32, unfused PAM; the tight-parity mode).
+    precision: str = "bf16"
+
+
+config = _Config()
+
+
+def set_precision(p: str) -> None:
+    if p not in ("bf16", "fp32"):
+        raise ValueError("precision must be 'bf16' or 'fp32'")
+    config.precision = p
+
+
+@contextmanager
+def precision(p: str):
+    old = config.precision
+    set_precision(p)
+    try:
+        yield
+    finally:
+        config.precision = old

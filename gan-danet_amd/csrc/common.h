@@ -1,0 +1,83 @@
+// Shared device helpers for the GAN-DANet gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GD_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPR (MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 4 bf16 = 2 VGPR
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned short gd_f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float gd_bf2f(unsigned short h) {
+    return __builtin_bit_cast(float, ((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned int gd_pack_bf2(float lo, float hi) {
+    return (unsigned int)gd_f2bf(lo) | ((unsigned int)gd_f2bf(hi) << 16);
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float gd_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gd_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double gd_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of one float; `red` = LDS scratch of >= blockDim/64 floats; result valid in ALL threads
+__device__ __forceinline__ float gd_block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = gd_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float gd_block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = gd_wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// ---- error plumbing for the C ABI -------------------------------------------------------------
+extern "C" void gd_set_error(const char* msg);
+#define GD_CHECK_ARG(cond, msg)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            gd_set_error(msg);           \
+            return -1;                   \
+        }                                \
+    } while (0)
+#define GD_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) {                             \
+            gd_set_error(hipGetErrorString(e_));            \
+            return -2;                                      \
+        }                                                   \
+    } while (0)
+
+static inline int gd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

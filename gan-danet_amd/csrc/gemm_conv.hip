@@ -1,0 +1,246 @@
+// Implicit-GEMM convolution for gfx950 ("NN" form): out[b][m][p] = sum_{tap,c} A[m][c][tap] * X~[c][p(+)tap]
+//
+// GEMM view: M = output channels, N = output pixels of ONE image (blockIdx.z = image), K = taps x channels.
+// NCHW keeps pixels contiguous, so the im2col operand is read coalesced along N and the result is stored
+// coalesced along N.  Block tile BM x 128 x 32, 256 threads = 4 waves, each wave a grid of 32x32 MFMA tiles.
+// Operands are staged global -> registers -> LDS (the fp32 -> bf16 conversion and the fused BatchNorm+ReLU
+// input transform happen in that register stage), LDS rows padded (80 B for bf16) so that both the
+// 16-byte staging writes and the 16-byte fragment reads are bank-conflict free.
+// Precision policies: BF16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) and FP32 (v_mfma_f32_32x32x2_f32,
+// bit-exact f32 fma chain) share every line except the fragment code.
+#include "common.h"
+#include "tile_mma.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+using gd::TILE_BK;
+using gd::TILE_BN;
+constexpr int BN = TILE_BN;
+constexpr int BK = TILE_BK;
+
+template <int BM, bool BF16>
+__global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
+    using P = gd::TilePol<BF16>;
+    using elem = typename P::elem;
+    constexpr int LD = P::LD;
+    constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
+    constexpr int TM = gd::TileGeom<BM>::TM;
+    constexpr int TN = gd::TileGeom<BM>::TN;
+    constexpr int KPT_A = BM / 8;   // A elements per thread per tile (BM*32/256)
+    constexpr int KPT_B = 16;       // B elements per thread per tile (128*32/256)
+
+    __shared__ __attribute__((aligned(16))) elem As[BM * LD];
+    __shared__ __attribute__((aligned(16))) elem Bs[BN * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const long HiWi = (long)d.Hi * d.Wi;
+    const int HoWo = d.Ho * d.Wo;
+
+    // ---- A loader coordinates: thread -> (row am, k group) ------------------------------------
+    const int am = tid % BM;
+    const int akg = tid / BM;  // 0 .. 256/BM-1, each KPT_A wide
+    const bool a_row_ok = (m0 + am) < d.M;
+    const float* a_row = d.a + (long)b * d.a_bs + (long)(m0 + am) * d.a_sm;
+
+    // ---- B loader coordinates: thread -> (pixel bn, k half) -----------------------------------
+    const int bn = tid & (BN - 1);
+    const int bkh = tid >> 7;  // 0/1, each 16 wide
+    const int p = n0 + bn;
+    const bool p_ok = p < HoWo;
+    const int oy = p_ok ? p / d.Wo : 0;
+    const int ox = p_ok ? p - oy * d.Wo : 0;
+    const float* x_img = d.x + (long)b * d.x_bs;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ktiles_per_tap = (d.Ck + BK - 1) / BK;
+    const int ntaps = d.ks * d.ks;
+    const int T = ntaps * ktiles_per_tap;
+
+    float ra[KPT_A];
+    float rb[KPT_B];
+
+    auto load_tile = [&](int t) {
+        const int tap = t / ktiles_per_tap;
+        const int c0 = (t - tap * ktiles_per_tap) * BK;
+        const int kh = tap / d.ks, kw = tap - kh * d.ks;
+        // A: weights gather (small, cache resident)
+        {
+            const float* ap = a_row + (long)tap * d.a_st;
+#pragma unroll
+            for (int i = 0; i < KPT_A; ++i) {
+                const int c = c0 + akg * KPT_A + i;
+                ra[i] = (a_row_ok && c < d.Ck) ? ap[(long)c * d.a_sc] : 0.f;
+            }
+        }
+        // B: im2col gather, coalesced along pixels
+        {
+            int iy, ix;
+            bool ok = p_ok;
+            if (!d.transposed) {
+                iy = oy * d.stride - d.pad + kh;
+                ix = ox * d.stride - d.pad + kw;
+            } else {
+                const int ty = oy + d.pad - kh, tx = ox + d.pad - kw;
+                ok = ok && ty >= 0 && tx >= 0 && (ty % d.stride == 0) && (tx % d.stride == 0);
+                iy = ty / d.stride;
+                ix = tx / d.stride;
+            }
+            ok = ok && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
+            const float* xp = x_img + (long)iy * d.Wi + ix;
+#pragma unroll
+            for (int i = 0; i < KPT_B; ++i) {
+                const int c = c0 + bkh * KPT_B + i;
+                float v = 0.f;
+                if (ok && c < d.Ck) {
+                    v = xp[(long)c * HiWi];
+                    if (d.in_scale) {
+                        v = fmaf(v, d.in_scale[c], d.in_shift[c]);
+                        if (d.in_relu) v = fmaxf(v, 0.f);
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tile = [&]() {
+        if constexpr (BF16) {
+            // A: KPT_A consecutive k at row am
+            unsigned short* ap = As + am * LD + akg * KPT_A;
+            if constexpr (KPT_A >= 8) {
+#pragma unroll
+                for (int i = 0; i < KPT_A; i += 8) {
+                    uint4 w;
+                    w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
+                    w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
+                    w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
+                    w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
+                    *reinterpret_cast<uint4*>(ap + i) = w;
+                }
+            } else {  // KPT_A == 4
+                uint2 w;
+                w.x = gd_pack_bf2(ra[0], ra[1]);
+                w.y = gd_pack_bf2(ra[2], ra[3]);
+                *reinterpret_cast<uint2*>(ap) = w;
+            }
+            unsigned short* bp = Bs + bn * LD + bkh * KPT_B;
+#pragma unroll
+            for (int i = 0; i < KPT_B; i += 8) {
+                uint4 w;
+                w.x = gd_pack_bf2(rb[i + 0], rb[i + 1]);
+                w.y = gd_pack_bf2(rb[i + 2], rb[i + 3]);
+                w.z = gd_pack_bf2(rb[i + 4], rb[i + 5]);
+                w.w = gd_pack_bf2(rb[i + 6], rb[i + 7]);
+                *reinterpret_cast<uint4*>(bp + i) = w;
+            }
+        } else {
+            float* ap = As + am * LD + akg * KPT_A;
+#pragma unroll
+            for (int i = 0; i < KPT_A; ++i) ap[i] = ra[i];
+            float* bp = Bs + bn * LD + bkh * KPT_B;
+#pragma unroll
+            for (int i = 0; i < KPT_B; ++i) bp[i] = rb[i];
+        }
+    };
+
+    auto compute_tile = [&]() { gd::tile_mma<BM, BF16>(As, Bs, wm, wn, r, h, acc); };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) load_tile(t + 1);  // global loads in flight under the MFMAs
+        compute_tile();
+        __syncthreads();
+        if (t + 1 < T) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    const float alpha = d.alpha ? *d.alpha : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pn = n0 + wn * TN * 32 + j * 32 + r;
+            if (pn >= HoWo) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                if (m >= d.Mstore) continue;
+                float v = acc[i][j][e] * alpha;
+                if (m < d.M) {
+                    if (d.bias) v += d.bias[m];
+                    if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HoWo + pn];
+                }
+                if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
+                const long idx = d.out_layout == 0 ? (long)b * d.y_bs + (long)m * HoWo + pn
+                                                   : (long)b * d.y_bs + (long)pn * d.ldo + m;
+                if (d.out_bf16) {
+                    reinterpret_cast<unsigned short*>(d.y)[idx] = gd_f2bf(v);
+                } else {
+                    float* yp = reinterpret_cast<float*>(d.y) + idx;
+                    if (d.accumulate) v += *yp;
+                    *yp = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM>
+int launch(const gd_conv_desc& d, hipStream_t s) {
+    dim3 grid(gd_cdiv((long)d.Ho * d.Wo, BN), gd_cdiv(d.Mstore, BM), d.B);
+    if (d.precision == GD_PREC_BF16)
+        hipLaunchKernelGGL((conv_nn_kernel<BM, true>), grid, dim3(256), 0, s, d);
+    else
+        hipLaunchKernelGGL((conv_nn_kernel<BM, false>), grid, dim3(256), 0, s, d);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
+    GD_CHECK_ARG(dp != nullptr, "gd_conv2d: null descriptor");
+    gd_conv_desc d = *dp;
+    if (d.Mstore < d.M) d.Mstore = d.M;
+    GD_CHECK_ARG(d.B > 0 && d.M > 0 && d.Ck > 0 && d.ks > 0 && d.stride > 0 && d.pad >= 0, "gd_conv2d: bad sizes");
+    GD_CHECK_ARG(d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0, "gd_conv2d: bad spatial sizes");
+    GD_CHECK_ARG(d.a && d.x && d.y, "gd_conv2d: null tensor");
+    GD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr), "gd_conv2d: in_scale/in_shift must come together");
+    GD_CHECK_ARG(d.precision == GD_PREC_FP32 || d.precision == GD_PREC_BF16, "gd_conv2d: bad precision");
+    GD_CHECK_ARG(d.out_layout == 0 || (d.out_layout == 1 && d.ldo >= d.Mstore), "gd_conv2d: bad output layout");
+    GD_CHECK_ARG(!(d.out_bf16 && d.accumulate), "gd_conv2d: accumulate needs an fp32 output");
+    GD_CHECK_ARG((long)d.Ho * d.Wo < (1L << 31) && d.B <= 65535, "gd_conv2d: image too large for one launch");
+    if (!d.transposed) {
+        // forward gather: the output size must be what this geometry produces
+        GD_CHECK_ARG((d.Hi + 2 * d.pad - d.ks) / d.stride + 1 == d.Ho && (d.Wi + 2 * d.pad - d.ks) / d.stride + 1 == d.Wo,
+                     "gd_conv2d: Ho/Wo do not match Hi/Wi, ks, stride, pad");
+    } else {
+        // transposed gather: X is the forward OUTPUT (Hi x Wi), y the forward input (Ho x Wo)
+        GD_CHECK_ARG((d.Ho + 2 * d.pad - d.ks) / d.stride + 1 == d.Hi && (d.Wo + 2 * d.pad - d.ks) / d.stride + 1 == d.Wi,
+                     "gd_conv2d: transposed geometry mismatch");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (d.Mstore <= 32) return launch<32>(d, s);
+    if (d.Mstore <= 64 || (d.Mstore % 128 != 0 && d.Mstore % 128 <= 64)) return launch<64>(d, s);
+    return launch<128>(d, s);
+}

@@ -1,0 +1,440 @@
+// Fused (flash-style) PAM attention for gfx950, bf16 MFMA with fp32 softmax statistics.
+//
+//   energy[i][j] = sum_d q[i][d] k[j][d]   (no 1/sqrt(d): generator.py:117)
+//   P = softmax_j(energy),  O[c][i] = sum_j V[c][j] P[i][j],  out = gamma * O + x   (generator.py:118-122)
+//
+// The N x N matrices are never materialised.  d is zero-padded to 32, C to a multiple of 32 (Cp).
+//
+// Forward: one workgroup = 4 waves = 128 queries (32 per wave), K/V streamed in 64-key tiles through LDS.
+//   S^T = K Q^T is computed with the KEY index on the accumulator rows and the QUERY on the lane, so
+//   * the row softmax is lane-local (+ one cross-half shuffle),
+//   * the probability tile is already the B operand of O^T = V P^T  (accumulator-as-operand, no LDS trip),
+//   * O^T comes out with the query on the lane: the online rescale is lane-local and the store to the NCHW
+//     output is coalesced along pixels.
+// Backward: one workgroup = 4 waves = 128 keys (32 per wave) holding dV^T and dK^T in accumulators while it
+//   sweeps the queries in 32-row tiles; S and dP are computed with the key on the lane, so P and dS are
+//   directly the B operands of dV^T += dO^T P and dK^T += Q^T dS; only dS crosses LDS (for dQ += dS K, which is
+//   accumulated across workgroups with fp32 atomics in 128-byte row segments).
+#include "common.h"
+#include "tile_mma.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+using gd::acc_row;
+using gd::bf16x8_native_t;
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_native_t, a),
+                                                   __builtin_bit_cast(bf16x8_native_t, b), c, 0, 0, 0);
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator -> the bf16 fragment of k-step s (k = accumulator ROW index,
+// element j of lane half h <-> row 16s + 8(j>>2) + 4h + (j&3))
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int s) {
+    union { bf16x8_t v; unsigned int u[4]; } f;
+    f.u[0] = gd_pack_bf2(a[8 * s + 0], a[8 * s + 1]);
+    f.u[1] = gd_pack_bf2(a[8 * s + 2], a[8 * s + 3]);
+    f.u[2] = gd_pack_bf2(a[8 * s + 4], a[8 * s + 5]);
+    f.u[3] = gd_pack_bf2(a[8 * s + 6], a[8 * s + 7]);
+    return f.v;
+}
+
+// A/B fragment whose k runs over an accumulator-row-ordered index stored contiguously in an LDS row:
+// elements [base + 4h .. +3] and [base + 8 + 4h .. +3]  (two 8-byte reads)
+__device__ __forceinline__ bf16x8_t read_perm_frag(const unsigned short* row, int base, int h) {
+    union { bf16x8_t v; uint2 u[2]; } f;
+    f.u[0] = *reinterpret_cast<const uint2*>(row + base + 4 * h);
+    f.u[1] = *reinterpret_cast<const uint2*>(row + base + 8 + 4 * h);
+    return f.v;
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+constexpr int F_KT = 64;    // keys per tile
+constexpr int F_KLD = 40;   // K row: 32 d + 8 pad (80 B) -> conflict-free 16-B fragment reads
+constexpr int F_VLD = 68;   // V row: 64 keys + 4 pad (136 B) -> conflict-free 8-B fragment reads
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* __restrict__ qt,
+                                                        const unsigned short* __restrict__ kt,
+                                                        const unsigned short* __restrict__ v, int N, int Npad, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ x,
+                                                        long x_bs, float* __restrict__ out, long out_bs,
+                                                        float* __restrict__ o_attn, float* __restrict__ lse) {
+    constexpr int CP = CT * 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[F_KT * F_KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[CP * F_VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const unsigned short* ktb = kt + (long)b * Npad * 32;
+    const unsigned short* vb = v + (long)b * CP * Npad;
+
+    // Q as the B operand of S^T = K Q^T: lane holds Q[query r][d = 16s + 8h + j]
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
+
+    f32x16_t o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
+    float m = -1e30f, l = 0.f;  // running max (log2 domain) and sum of this lane's query
+
+    const int nkt = (N + F_KT - 1) / F_KT;
+
+    // staging registers: K tile = 256 x 16 B; V tile = CP*8 chunks of 16 B = CT per thread
+    uint4 kreg;
+    uint4 vreg[CT];
+    const int k_key = tid >> 2, k_chunk = tid & 3;
+    auto load_tile = [&](int t) {
+        const int k0 = t * F_KT;
+        kreg = *reinterpret_cast<const uint4*>(ktb + (long)(k0 + k_key) * 32 + k_chunk * 8);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = tid + i * 256;
+            const int c = idx >> 3, qd = idx & 7;
+            vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)c * Npad + k0 + qd * 8);
+        }
+    };
+    auto store_tile = [&]() {
+        *reinterpret_cast<uint4*>(Ks + k_key * F_KLD + k_chunk * 8) = kreg;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = tid + i * 256;
+            const int c = idx >> 3, qd = idx & 7;
+            uint2* dst = reinterpret_cast<uint2*>(Vs + c * F_VLD + qd * 8);  // 136-B rows: 8-B aligned only
+            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
+            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        if (t + 1 < nkt) load_tile(t + 1);
+
+        // ---- S^T tiles (keys on rows, query on the lane) ----
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t kf =
+                    *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
+                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
+            }
+        }
+        // ---- online softmax (log2 domain) ----
+        const bool tail = (t + 1) * F_KT > N;
+        float mloc = -1e30f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float sv = sacc[sub][e] * LOG2E;
+                if (tail && (t * F_KT + sub * 32 + acc_row(e, h)) >= N) sv = -1e30f;
+                sacc[sub][e] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m, mloc);
+        if (__any(m_new > m)) {  // wave-uniform: skip the O rescale when no query's max moved
+            const float alpha = exp2f(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+            m = m_new;
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = exp2f(sacc[sub][e] - m);
+                sacc[sub][e] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l += lsum;
+
+        // ---- O^T += V P^T : A = V rows (channel), k = keys in accumulator-row order; B = P fragments ----
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const unsigned short* vrow = Vs + (ct * 32 + r) * F_VLD;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8_t vf = read_perm_frag(vrow, sub * 32 + s * 16, h);
+                    o[ct] = mfma_bf16(vf, pf[sub][s], o[ct]);
+                }
+        }
+        __syncthreads();
+        if (t + 1 < nkt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: O / l, residual, log-sum-exp ----
+    const int qi = q0 + r;
+    if (qi < N) {
+        const float inv_l = 1.f / l;
+        const float g = *gamma;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = ct * 32 + acc_row(e, h);
+                if (c < C) {
+                    const float val = o[ct][e] * inv_l;
+                    o_attn[((long)b * C + c) * N + qi] = val;
+                    out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
+                }
+            }
+        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
+    }
+}
+
+// =====================================================================================================
+// backward
+// =====================================================================================================
+constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
+constexpr int B_TLD = 36;   // transposed tiles rows [..][32 i] (72 B): 8-B reads, conflict free
+constexpr int B_SLD = 40;   // dS tile rows [i][32 j] (80 B)
+
+template <int CT>
+__global__ __launch_bounds__(256, 1) void pam_bwd_kernel(
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
+    const unsigned short* __restrict__ kn, const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_,
+    const unsigned short* __restrict__ don, const float* __restrict__ lse, const float* __restrict__ delta, int N,
+    int Npad, float* __restrict__ dqt, float* __restrict__ dkn, float* __restrict__ dv) {
+    constexpr int CP = CT * 32;
+    constexpr int DLD = CP + 8;  // dO tile rows [i][CP c] (+16 B): 16-B reads conflict free
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
+    __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dSs[4 * 32 * B_SLD];
+    __shared__ float Ls[32], Ds[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * 128 + wave * 32;  // this wave's 32 keys
+    const long nb = (long)b * Npad;
+
+    // ---- persistent per-wave operands -------------------------------------------------------------------
+    // K as B operand of S = Q K^T (col j = r, k = d)
+    bf16x8_t kfB[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
+    // V as B operand of dP = dO V^T (col j = r, k = c)
+    bf16x8_t vfB[2 * CT];
+#pragma unroll
+    for (int s = 0; s < 2 * CT; ++s)
+        vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + s * 16 + 8 * h);
+    // K as B operand of dQ = dS K (col d = r, k = j in natural order): kn[d][j0 + 16s + 8h + jj]
+    bf16x8_t knB[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        knB[s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + s * 16 + 8 * h);
+
+    f32x16_t dvacc[CT], dkacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[e] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
+
+    const bool key_ok = (j0 + r) < N;
+    unsigned short* dSw = dSs + wave * 32 * B_SLD;
+
+    const int nqt = (N + 31) / 32;
+    for (int qtile = 0; qtile < nqt; ++qtile) {
+        const int i0 = qtile * 32;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage the query tile: Q [i][d], Q^T [d][i], dO [i][c], dO^T [c][i], lse, delta --------------
+        if (tid < 128) {  // Q: 32 rows x 64 B = 128 chunks of 16 B
+            const int i = tid >> 2, ch = tid & 3;
+            *reinterpret_cast<uint4*>(Qs + i * B_QLD + ch * 8) =
+                *reinterpret_cast<const uint4*>(qt + (nb + i0 + i) * 32 + ch * 8);
+        } else {          // Q^T: 32 rows (d) x 64 B
+            const int t2 = tid - 128;
+            const int d = t2 >> 2, ch = t2 & 3;
+            const uint4 w = *reinterpret_cast<const uint4*>(qn + ((long)b * 32 + d) * Npad + i0 + ch * 8);
+            uint2* dst = reinterpret_cast<uint2*>(QTs + d * B_TLD + ch * 8);
+            dst[0] = make_uint2(w.x, w.y);
+            dst[1] = make_uint2(w.z, w.w);
+        }
+        // dO: 32 rows x CP*2 B = 32*CT*4 chunks
+#pragma unroll
+        for (int it = 0; it < (CT + 1) / 2; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < 32 * CT * 4) {
+                const int i = idx / (CT * 4), ch = idx - i * (CT * 4);
+                *reinterpret_cast<uint4*>(dOs + i * DLD + ch * 8) =
+                    *reinterpret_cast<const uint4*>(dot_ + (nb + i0 + i) * CP + ch * 8);
+            }
+        }
+        // dO^T: CP rows x 64 B = CP*4 chunks
+#pragma unroll
+        for (int it = 0; it < (CT + 1) / 2; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < CP * 4) {
+                const int c = idx >> 2, ch = idx & 3;
+                const uint4 w = *reinterpret_cast<const uint4*>(don + ((long)b * CP + c) * Npad + i0 + ch * 8);
+                uint2* dst = reinterpret_cast<uint2*>(dOTs + c * B_TLD + ch * 8);
+                dst[0] = make_uint2(w.x, w.y);
+                dst[1] = make_uint2(w.z, w.w);
+            }
+        }
+        if (tid < 32) {
+            const int i = i0 + tid;
+            Ls[tid] = i < N ? lse[(long)b * N + i] : 0.f;
+            Ds[tid] = i < N ? delta[(long)b * N + i] : 0.f;
+        }
+        __syncthreads();
+
+        // ---- S' = Q K^T - lse  (rows i, lane j) ; P = exp(S') ---------------------------------------------
+        f32x16_t sacc, dpacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = -Ls[acc_row(e, h)];
+            dpacc[e] = -Ds[acc_row(e, h)];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
+            sacc = mfma_bf16(qa, kfB[s], sacc);
+        }
+        // ---- dP - delta = dO V^T - delta ----------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 2 * CT; ++s) {
+            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
+            dpacc = mfma_bf16(da, vfB[s], dpacc);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool ok = key_ok && (i0 + acc_row(e, h)) < N;
+            const float p = ok ? exp2f(sacc[e] * LOG2E) : 0.f;
+            sacc[e] = p;
+            dpacc[e] = p * dpacc[e];  // dS
+        }
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            pf[s] = pack_frag(sacc, s);
+            dsf[s] = pack_frag(dpacc, s);
+        }
+        // ---- dV^T[c][j] += dO^T[c][i] P[i][j] ------------------------------------------------------------
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const unsigned short* row = dOTs + (ct * 32 + r) * B_TLD;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_perm_frag(row, s * 16, h), pf[s], dvacc[ct]);
+        }
+        // ---- dK^T[d][j] += Q^T[d][i] dS[i][j] ------------------------------------------------------------
+        {
+            const unsigned short* row = QTs + r * B_TLD;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dkacc = mfma_bf16(read_perm_frag(row, s * 16, h), dsf[s], dkacc);
+        }
+        // ---- dQ[i][d] += dS[i][j] K[j][d] : dS through LDS (row i, k = j natural) -------------------------
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dSw[acc_row(e, h) * B_SLD + r] = gd_f2bf(dpacc[e]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private tile)
+        __builtin_amdgcn_wave_barrier();
+        f32x16_t dqacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t dsa = *reinterpret_cast<const bf16x8_t*>(dSw + r * B_SLD + s * 16 + 8 * h);
+            dqacc = mfma_bf16(dsa, knB[s], dqacc);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + acc_row(e, h);
+            if (i < N) atomicAdd(dqt + (nb + i) * 32 + r, dqacc[e]);
+        }
+    }
+
+    // ---- write dV^T (channel-major, coalesced along keys) and dK^T ----------------------------------------
+    const int j = j0 + r;
+    if (j < Npad) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+    }
+}
+
+}  // namespace
+
+#define PAM_DISPATCH_CT(CT_, CALL)                         \
+    switch (CT_) {                                         \
+        case 1: { constexpr int CT = 1; CALL; } break;     \
+        case 2: { constexpr int CT = 2; CALL; } break;     \
+        case 3: { constexpr int CT = 3; CALL; } break;     \
+        case 4: { constexpr int CT = 4; CALL; } break;     \
+        case 5: { constexpr int CT = 5; CALL; } break;     \
+        case 6: { constexpr int CT = 6; CALL; } break;     \
+        default: gd_set_error("pam: Cp must be 32..192"); return -1; \
+    }
+
+extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
+                                const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn,
+                                float* lse, void* stream) {
+    GD_CHECK_ARG(qt && kt && v && gamma && x && out && o_attn && lse, "gd_pam_flash_fwd: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 128 >= N");
+    GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
+    dim3 grid(Npad / 128, B);
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                 (const unsigned short*)qt, (const unsigned short*)kt,
+                                                 (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn,
+                                                 lse));
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
+                                const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
+                                int Npad, int Cp, float* dqt, float* dkn, float* dv, void* stream) {
+    GD_CHECK_ARG(qt && kt && qn && kn && vt && dot_ && don && lse && delta && dqt && dkn && dv, "gd_pam_flash_bwd: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 128 >= N");
+    GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
+    dim3 grid(Npad / 128, B);
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                 (const unsigned short*)qt, (const unsigned short*)kt,
+                                                 (const unsigned short*)qn, (const unsigned short*)kn,
+                                                 (const unsigned short*)vt, (const unsigned short*)dot_,
+                                                 (const unsigned short*)don, lse, delta, N, Npad, dqt, dkn, dv));
+    GD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,478 @@
+// Pointwise / small-reduction kernels for gfx950: activations, axpby, slab copies, row softmax (fwd/bwd),
+// dot/sum reductions, transposes, the losses of the G+D step (BCE-with-logits, MSE, L1, TV, SSIM),
+// AdamW, and the fp32 -> bf16 pack/transpose feeding the fused PAM kernels.  All HBM-bound: grid-stride,
+// 16-byte accesses where alignment allows, two-stage deterministic reductions (no float atomics).
+#include "common.h"
+#include "../../include/gandanet.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;  // stage-1 workgroups of the scalar reductions
+
+static inline int grid_for(long n, int per_block = 256 * 4) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == GD_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == GD_ACT_LEAKY02) return v >= 0.f ? v : 0.2f * v;
+    return v;
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = act_f(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long n,
+                               int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float o = y[i], g = dy[i];
+        float v = g;
+        if (act == GD_ACT_RELU) v = o > 0.f ? g : 0.f;
+        else if (act == GD_ACT_LEAKY02) v = o >= 0.f ? g : 0.2f * g;  // sign(y) == sign(x) for leaky
+        dx[i] = v;
+    }
+}
+__global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = b == 0.f ? a * x[i] : fmaf(a, x[i], b * y[i]);
+}
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, long n,
+                                 int accumulate) {
+    const float k = *s;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = accumulate ? fmaf(k, x[i], y[i]) : k * x[i];
+}
+// dst[b][r][c] = src[b][r][c] for r < R, c < Cc with independent leading dimensions (compaction of padded planes)
+__global__ void copy_rows_kernel(const float* __restrict__ src, long s_bs, long s_ld, float* __restrict__ dst, long d_bs,
+                                 long d_ld, int R, int Cc) {
+    const int b = blockIdx.y;
+    const long total = (long)R * Cc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Cc), c = (int)(i - (long)r * Cc);
+        dst[(long)b * d_bs + (long)r * d_ld + c] = src[(long)b * s_bs + (long)r * s_ld + c];
+    }
+}
+__global__ void copy_slab_kernel(const float* __restrict__ src, long s_bs, float* __restrict__ dst, long d_bs, long chw,
+                                 int accumulate) {
+    const int b = blockIdx.y;
+    const float* s = src + (long)b * s_bs;
+    float* d = dst + (long)b * d_bs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long)gridDim.x * blockDim.x)
+        d[i] = accumulate ? d[i] + s[i] : s[i];
+}
+
+// ---- row softmax ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int cols,
+                                                          float sign) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float* p = x + row * cols;
+    float* q = y + row * cols;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, sign * p[i]);
+    m = gd_block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) s += __expf(sign * p[i] - m);
+    s = gd_block_sum(s, red);
+    const float inv = 1.f / s;
+    for (int i = threadIdx.x; i < cols; i += 256) q[i] = __expf(sign * p[i] - m) * inv;
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                              float* __restrict__ dx, int cols, float sign) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float* pp = p + row * cols;
+    const float* pd = dp + row * cols;
+    float* po = dx + row * cols;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) s = fmaf(pp[i], pd[i], s);
+    s = gd_block_sum(s, red);
+    for (int i = threadIdx.x; i < cols; i += 256) po[i] = sign * pp[i] * (pd[i] - s);
+}
+
+// ---- generic two-stage scalar reductions -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ ws, int nparts, float scale,
+                                                          float* __restrict__ out, int accumulate) {
+    __shared__ double redd[4];
+    double a = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += ws[i];
+    a = gd_wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)((redd[0] + redd[1] + redd[2] + redd[3]) * (double)scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                 float* __restrict__ ws) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        s = b ? fmaf(a[i], b[i], s) : s + a[i];
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+
+// ---- transposes -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ s, float* __restrict__ t, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float* sp = s + (long)b * R * Cc;
+    float* tp = t + (long)b * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? sp[(long)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < R) tp[(long)c * R + r] = tile[tx][i];
+    }
+}
+__global__ void add_transpose_kernel(const float* __restrict__ a, float* __restrict__ out, int n) {
+    const int b = blockIdx.y;
+    const float* ap = a + (long)b * n * n;
+    float* op = out + (long)b * n * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n), c = (int)(i - (long)r * n);
+        op[i] = ap[i] + ap[(long)c * n + r];
+    }
+}
+
+// fp32 (R, Cc) plane -> bf16 plain copy (zero padded to Rp x ldp) and/or bf16 transpose (zero padded Ccp x ldt)
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ s, long s_bs, int R, int Cc,
+                                                       const float* __restrict__ scale, unsigned short* __restrict__ plain,
+                                                       int Rp, int ldp, unsigned short* __restrict__ tr, int Ccp, int ldt) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float* sp = s + (long)b * s_bs;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float k = scale ? *scale : 1.f;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < R && c < Cc) ? k * sp[(long)r * Cc + c] : 0.f;
+        tile[i][tx] = v;
+        if (plain && r < Rp && c < ldp) plain[(long)b * Rp * ldp + (long)r * ldp + c] = gd_f2bf(v);
+    }
+    if (tr) {
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, r = r0 + tx;
+            if (c < Ccp && r < ldt) tr[(long)b * Ccp * ldt + (long)c * ldt + r] = gd_f2bf(tile[tx][i]);
+        }
+    }
+}
+
+// D[b][i] = sum_c a[b][c][i] * o[b][c][i]  (per-pixel channel dot) ; delta = gamma * D
+__global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__ a, long a_bs, const float* __restrict__ o,
+                                                      long o_bs, int C, int N, const float* __restrict__ gamma,
+                                                      float* __restrict__ draw, float* __restrict__ delta) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* ap = a + (long)b * a_bs + i;
+    const float* op = o + (long)b * o_bs + i;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(ap[(long)c * N], op[(long)c * N], s);
+    draw[(long)b * N + i] = s;
+    delta[(long)b * N + i] = s * (*gamma);
+}
+
+// ---- losses --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, long n, float label, float inv_n,
+                                                 float* __restrict__ dz, float* __restrict__ ws) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = z[i];
+        s += fmaxf(v, 0.f) - v * label + log1pf(expf(-fabsf(v)));
+        if (dz) dz[i] = (1.f / (1.f + expf(-v)) - label) * inv_n;
+    }
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+template <bool L1>
+__global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                       float inv_n, float* __restrict__ da, float* __restrict__ ws) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float dv = a[i] - b[i];
+        if (L1) {
+            s += fabsf(dv);
+            if (da) da[i] = dv > 0.f ? inv_n : (dv < 0.f ? -inv_n : 0.f);
+        } else {
+            s = fmaf(dv, dv, s);
+            if (da) da[i] = 2.f * dv * inv_n;
+        }
+    }
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+// TV: sum of squared vertical / horizontal neighbour differences; gradient of
+//   w*2*(h_tv/count_h + w_tv/count_w)/B  written per pixel (gather of the <=4 differences it appears in)
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ x, long planes, int H, int W, float kh, float kw,
+                                                float* __restrict__ dx, float* __restrict__ ws_h, float* __restrict__ ws_w) {
+    __shared__ float red[8];
+    const long total = planes * H * W;
+    float sh = 0.f, sw = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        const float v = x[i];
+        float g = 0.f;
+        if (yy + 1 < H) { const float d = x[i + W] - v; sh = fmaf(d, d, sh); g -= 2.f * kh * d; }
+        if (yy > 0) { const float d = v - x[i - W]; g += 2.f * kh * d; }
+        if (xx + 1 < W) { const float d = x[i + 1] - v; sw = fmaf(d, d, sw); g -= 2.f * kw * d; }
+        if (xx > 0) { const float d = v - x[i - 1]; g += 2.f * kw * d; }
+        if (dx) dx[i] = g;
+    }
+    sh = gd_block_sum(sh, red);
+    sw = gd_block_sum(sw, red);
+    if (threadIdx.x == 0) { ws_h[blockIdx.x] = sh; ws_w[blockIdx.x] = sw; }
+}
+__global__ __launch_bounds__(256) void tv_final_kernel(const float* __restrict__ ws_h, const float* __restrict__ ws_w,
+                                                      int nparts, float kh, float kw, float* __restrict__ out) {
+    __shared__ double redd[8];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { a += ws_h[i]; b += ws_w[i]; }
+    a = gd_wave_sum_d(a);
+    b = gd_wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { redd[threadIdx.x >> 6] = a; redd[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[0] = (float)((redd[0] + redd[1] + redd[2] + redd[3]) * (double)kh + (redd[4] + redd[5] + redd[6] + redd[7]) * (double)kw);
+}
+
+struct SsimWin { float g[16]; int n; };
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W,
+                                                  SsimWin win, float* __restrict__ ws) {
+    __shared__ float red[8];
+    const long plane = blockIdx.y;
+    const float* pa = a + plane * (long)H * W;
+    const float* pb = b + plane * (long)H * W;
+    const int half = win.n / 2;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)H * W; i += (long)gridDim.x * 256) {
+        const int yy = (int)(i / W), xx = (int)(i - (long)yy * W);
+        float m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+        for (int dy = 0; dy < win.n; ++dy) {
+            const int y2 = yy + dy - half;
+            if (y2 < 0 || y2 >= H) continue;
+            for (int dx = 0; dx < win.n; ++dx) {
+                const int x2 = xx + dx - half;
+                if (x2 < 0 || x2 >= W) continue;
+                const float w = win.g[dy] * win.g[dx];
+                const float u = pa[(long)y2 * W + x2], v = pb[(long)y2 * W + x2];
+                m1 = fmaf(w, u, m1); m2 = fmaf(w, v, m2);
+                s11 = fmaf(w, u * u, s11); s22 = fmaf(w, v * v, s22); s12 = fmaf(w, u * v, s12);
+            }
+        }
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+        const float v1 = s11 - m1s, v2 = s22 - m2s, v12 = s12 - m12;
+        s += ((2.f * m12 + c1) * (2.f * v12 + c2)) / ((m1s + m2s + c1) * (v1 + v2 + c2));
+    }
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// ---- AdamW -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float beta1, float beta2, float eps, float wd, float gscale,
+                                                   float inv_bc1, float inv_sqrt_bc2) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        pi -= (lr * inv_bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+}  // namespace
+
+#define GD_S ((hipStream_t)stream)
+
+extern "C" int gd_act_fwd(const float* x, float* y, long n, int act, void* stream) {
+    GD_CHECK_ARG(x && y && n > 0, "gd_act_fwd: bad arguments");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, x, y, n, act);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_act_bwd(const float* y, const float* dy, float* dx, long n, int act, void* stream) {
+    GD_CHECK_ARG(y && dy && dx && n > 0, "gd_act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, y, dy, dx, n, act);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_axpby(const float* x, float a, float* y, float b, long n, void* stream) {
+    GD_CHECK_ARG(x && y && n > 0, "gd_axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, x, a, y, b, n);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_scale_dev(const float* x, const float* s_dev, float* y, long n, int accumulate, void* stream) {
+    GD_CHECK_ARG(x && y && s_dev && n > 0, "gd_scale_dev: bad arguments");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, x, s_dev, y, n, accumulate);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_copy_rows(const float* src, long s_bs, long s_ld, float* dst, long d_bs, long d_ld, int B, int R, int Cc,
+                            void* stream) {
+    GD_CHECK_ARG(src && dst && B > 0 && B <= 65535 && R > 0 && Cc > 0 && s_ld >= Cc && d_ld >= Cc, "gd_copy_rows: bad arguments");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long)R * Cc), B), dim3(256), 0, GD_S, src, s_bs, s_ld, dst, d_bs,
+                       d_ld, R, Cc);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_copy_slab(const float* src, long s_bs, float* dst, long d_bs, int B, long chw, int accumulate,
+                            void* stream) {
+    GD_CHECK_ARG(src && dst && B > 0 && B <= 65535 && chw > 0, "gd_copy_slab: bad arguments");
+    hipLaunchKernelGGL(copy_slab_kernel, dim3(grid_for(chw), B), dim3(256), 0, GD_S, src, s_bs, dst, d_bs, chw, accumulate);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_softmax_rows(const float* x, float* y, long rows, int cols, float sign, void* stream) {
+    GD_CHECK_ARG(x && y && rows > 0 && rows < (1L << 31) && cols > 0, "gd_softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, GD_S, x, y, cols, sign);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_softmax_rows_bwd(const float* p, const float* dp, float* dx, long rows, int cols, float sign,
+                                   void* stream) {
+    GD_CHECK_ARG(p && dp && dx && rows > 0 && rows < (1L << 31) && cols > 0, "gd_softmax_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, GD_S, p, dp, dx, cols, sign);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_dot(const float* a, const float* b, long n, float* out, int accumulate, float* ws, void* stream) {
+    GD_CHECK_ARG(a && out && ws && n > 0, "gd_dot: bad arguments");
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, GD_S, a, b, n, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, g, 1.f, out, accumulate);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_transpose(const float* s, float* t, int B, int R, int Cc, void* stream) {
+    GD_CHECK_ARG(s && t && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_transpose: bad arguments");
+    GD_CHECK_ARG(gd_cdiv(R, 32) <= 65535, "gd_transpose: too many rows");
+    hipLaunchKernelGGL(transpose_kernel, dim3(gd_cdiv(Cc, 32), gd_cdiv(R, 32), B), dim3(256), 0, GD_S, s, t, R, Cc);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_add_transpose(const float* a, float* out, int B, int n, void* stream) {
+    GD_CHECK_ARG(a && out && a != out && B > 0 && B <= 65535 && n > 0, "gd_add_transpose: bad arguments");
+    hipLaunchKernelGGL(add_transpose_kernel, dim3(grid_for((long)n * n), B), dim3(256), 0, GD_S, a, out, n);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, void* plain,
+                            int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, void* stream) {
+    GD_CHECK_ARG(s && (plain || transposed) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_bf16: bad arguments");
+    GD_CHECK_ARG(!plain || (Rp_plain >= R && ld_plain >= Cc), "gd_pack_bf16: plain padding smaller than the data");
+    GD_CHECK_ARG(!transposed || (Ccp_t >= Cc && ld_t >= R), "gd_pack_bf16: transposed padding smaller than the data");
+    int rows = R, cols = Cc;
+    if (plain) { rows = rows > Rp_plain ? rows : Rp_plain; cols = cols > ld_plain ? cols : ld_plain; }
+    if (transposed) { rows = rows > ld_t ? rows : ld_t; cols = cols > Ccp_t ? cols : Ccp_t; }
+    GD_CHECK_ARG(gd_cdiv(rows, 32) <= 65535, "gd_pack_bf16: too many rows");
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
+                       scale_dev, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t, ld_t);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
+                           float* d_raw, float* delta, void* stream) {
+    GD_CHECK_ARG(a && o && gamma && d_raw && delta && B > 0 && B <= 65535 && C > 0 && N > 0, "gd_chan_dot: bad arguments");
+    hipLaunchKernelGGL(chan_dot_kernel, dim3(gd_cdiv(N, 256), B), dim3(256), 0, GD_S, a, a_bs, o, o_bs, C, N, gamma, d_raw,
+                       delta);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_bce_logits(const float* z, long n, float label, float* out, float* dz, float* ws, void* stream) {
+    GD_CHECK_ARG(z && out && ws && n > 0, "gd_bce_logits: bad arguments");
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL(bce_kernel, dim3(g), dim3(256), 0, GD_S, z, n, label, 1.f / (float)n, dz, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, g, 1.f / (float)n, out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_mse(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && n > 0, "gd_mse: bad arguments");
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL((diff_loss_kernel<false>), dim3(g), dim3(256), 0, GD_S, a, b, n, 1.f / (float)n, da, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, g, 1.f / (float)n, out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_l1(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && n > 0, "gd_l1: bad arguments");
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL((diff_loss_kernel<true>), dim3(g), dim3(256), 0, GD_S, a, b, n, 1.f / (float)n, da, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, g, 1.f / (float)n, out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_tv(const float* x, int B, int C, int H, int W, float weight, float* out, float* dx, float* ws,
+                     void* stream) {
+    GD_CHECK_ARG(x && out && ws && B > 0 && C > 0 && H > 1 && W > 1, "gd_tv: bad arguments");
+    const long planes = (long)B * C;
+    const double count_h = (double)planes * (H - 1) * W, count_w = (double)planes * H * (W - 1);
+    const float kh = (float)(weight * 2.0 / count_h / B), kw = (float)(weight * 2.0 / count_w / B);
+    const long n = planes * H * W;
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL(tv_kernel, dim3(g), dim3(256), 0, GD_S, x, planes, H, W, kh, kw, dx, ws, ws + RED_BLOCKS);
+    hipLaunchKernelGGL(tv_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, ws + RED_BLOCKS, g, kh, kw, out);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_ssim(const float* a, const float* b, int BC, int H, int W, int window, float* out, float* ws,
+                       void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && BC > 0 && H > 0 && W > 0, "gd_ssim: bad arguments");
+    GD_CHECK_ARG(window > 0 && window <= 15 && (window & 1), "gd_ssim: window must be odd and <= 15");
+    SsimWin win;
+    win.n = window;
+    // SSIM._gaussian (losses.py:98-101): fp32 exp, normalised by the fp32 sum
+    float tmp[16], sum = 0.f;
+    for (int i = 0; i < window; ++i) {
+        const float d = (float)(i - window / 2);
+        tmp[i] = expf(-(d * d) / (2.f * 1.5f * 1.5f));
+        sum += tmp[i];
+    }
+    for (int i = 0; i < 16; ++i) win.g[i] = i < window ? tmp[i] / sum : 0.f;
+    int gx = (int)(((long)H * W + 255) / 256);
+    if (gx > 64) gx = 64;
+    while ((long)gx * BC > 2048 && gx > 1) gx >>= 1;
+    GD_CHECK_ARG((long)gx * BC <= 2048 && BC <= 65535, "gd_ssim: too many planes for the workspace");
+    hipLaunchKernelGGL(ssim_kernel, dim3(gx, BC), dim3(256), 0, GD_S, a, b, H, W, win, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, gx * BC, 1.f / ((float)BC * (float)H * (float)W),
+                       out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    GD_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "gd_adamw: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    GD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,297 @@
+// Resampling kernels for gfx950: bicubic (A = -0.75, half-pixel centres, border-clamped taps) and
+// bilinear (align_corners = False) resize forward + gather-form backward, 2x2 max-pool.
+// HBM-bound; one thread per output element, planes walked contiguously along x (coalesced).
+// The backward kernels are GATHERS (each input pixel sums the output pixels that read it, found by
+// re-running the forward index computation over a conservative window) -- no atomics, deterministic.
+#include "common.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+constexpr int WMAX = 14;  // widest per-axis window the gather backward supports
+
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// forward taps of one output coordinate o: indices idx[4] (clamped) and weights w[4]
+__device__ __forceinline__ void cubic_taps(int o, float rs, int n_in, int (&idx)[4], float (&w)[4]) {
+    const float src = rs * ((float)o + 0.5f) - 0.5f;
+    const float fl = floorf(src);
+    cubic_w(src - fl, w);
+    const int i0 = (int)fl;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) idx[t] = clampi(i0 - 1 + t, 0, n_in - 1);
+}
+
+__device__ __forceinline__ void linear_taps(int o, float rs, int n_in, int& i0, int& i1, float& lam) {
+    float src = rs * ((float)o + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+    lam = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bicubic_fwd_kernel(const float* __restrict__ x, int Hi, int Wi,
+                                                         float* __restrict__ y, int Ho, int Wo, float rsh, float rsw) {
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ox >= Wo) return;
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    cubic_taps(oy, rsh, Hi, iy, wy);
+    cubic_taps(ox, rsw, Wi, ix, wx);
+    const float* p = x + bc * (long)Hi * Wi;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float* row = p + (long)iy[a] * Wi;
+        float r = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r = fmaf(row[ix[c]], wx[c], r);
+        acc = fmaf(r, wy[a], acc);
+    }
+    y[bc * (long)Ho * Wo + (long)oy * Wo + ox] = acc;
+}
+
+// conservative window of output coordinates that may read input coordinate i (cubic: |src - i| < 2 + clamp)
+__device__ __forceinline__ void cubic_window(int i, float rs, int n_in, int n_out, int& lo, int& hi) {
+    const float inv = 1.f / rs;
+    lo = (i == 0) ? 0 : (int)floorf(((float)i - 2.f + 0.5f) * inv - 0.5f) - 1;
+    hi = (i == n_in - 1) ? n_out - 1 : (int)ceilf(((float)i + 2.f + 0.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > n_out - 1 ? n_out - 1 : hi;
+}
+__device__ __forceinline__ void linear_window(int i, float rs, int n_in, int n_out, int& lo, int& hi) {
+    const float inv = 1.f / rs;
+    lo = (i == 0) ? 0 : (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1;
+    hi = (i == n_in - 1) ? n_out - 1 : (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > n_out - 1 ? n_out - 1 : hi;
+}
+
+template <bool CUBIC>
+__global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const float* __restrict__ dy, int Hi, int Wi,
+                                                               float* __restrict__ dx, int Ho, int Wo, float rsh,
+                                                               float rsw) {
+    // (Hi, Wi) = forward INPUT size = size of dx; (Ho, Wo) = forward output size = size of dy
+    const int ix = blockIdx.x * 256 + threadIdx.x;
+    const int iy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ix >= Wi) return;
+    int xlo, xhi, ylo, yhi;
+    if (CUBIC) {
+        cubic_window(ix, rsw, Wi, Wo, xlo, xhi);
+        cubic_window(iy, rsh, Hi, Ho, ylo, yhi);
+    } else {
+        linear_window(ix, rsw, Wi, Wo, xlo, xhi);
+        linear_window(iy, rsh, Hi, Ho, ylo, yhi);
+    }
+    // x weights of every candidate column, once
+    float wxs[WMAX];
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) {
+        const int ox = xlo + k;
+        float w = 0.f;
+        if (ox <= xhi) {
+            if (CUBIC) {
+                int idx[4];
+                float ww[4];
+                cubic_taps(ox, rsw, Wi, idx, ww);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w += (idx[t] == ix) ? ww[t] : 0.f;
+            } else {
+                int i0, i1;
+                float lam;
+                linear_taps(ox, rsw, Wi, i0, i1, lam);
+                w += (i0 == ix) ? (1.f - lam) : 0.f;
+                w += (i1 == ix) ? lam : 0.f;
+            }
+        }
+        wxs[k] = w;
+    }
+    const float* g = dy + bc * (long)Ho * Wo;
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        float wy = 0.f;
+        if (CUBIC) {
+            int idx[4];
+            float ww[4];
+            cubic_taps(oy, rsh, Hi, idx, ww);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wy += (idx[t] == iy) ? ww[t] : 0.f;
+        } else {
+            int i0, i1;
+            float lam;
+            linear_taps(oy, rsh, Hi, i0, i1, lam);
+            wy += (i0 == iy) ? (1.f - lam) : 0.f;
+            wy += (i1 == iy) ? lam : 0.f;
+        }
+        if (wy == 0.f) continue;
+        const float* row = g + (long)oy * Wo;
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k) {
+            const int ox = xlo + k;
+            if (ox <= xhi) r = fmaf(row[ox], wxs[k], r);
+        }
+        acc = fmaf(r, wy, acc);
+    }
+    dx[bc * (long)Hi * Wi + (long)iy * Wi + ix] = acc;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int Hi, int Wi,
+                                                          float* __restrict__ y, int Ho, int Wo, float rsh, float rsw,
+                                                          int accumulate) {
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ox >= Wo) return;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    linear_taps(oy, rsh, Hi, y0, y1, ly);
+    linear_taps(ox, rsw, Wi, x0, x1, lx);
+    const float* p = x + bc * (long)Hi * Wi;
+    const float* r0 = p + (long)y0 * Wi;
+    const float* r1 = p + (long)y1 * Wi;
+    const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
+    const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
+    float v = top * (1.f - ly) + bot * ly;
+    float* q = y + bc * (long)Ho * Wo + (long)oy * Wo + ox;
+    if (accumulate) v += *q;
+    *q = v;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int Hi, int Wi,
+                                                          float* __restrict__ y) {
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ox >= Wo) return;
+    const float* p = x + bc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    const float2 b = *reinterpret_cast<const float2*>(p + Wi);
+    y[bc * (long)Ho * Wo + (long)oy * Wo + ox] = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y));
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          int Hi, int Wi, float* __restrict__ dx) {
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ox >= Wo) return;
+    const long base = bc * (long)Hi * Wi + (long)(2 * oy) * Wi + 2 * ox;
+    const float2 a = *reinterpret_cast<const float2*>(x + base);
+    const float2 b = *reinterpret_cast<const float2*>(x + base + Wi);
+    const float g = dy[bc * (long)Ho * Wo + (long)oy * Wo + ox];
+    // first maximum in row-major order takes the gradient (ATen's max_pool2d_with_indices tie rule)
+    int arg = 0;
+    float m = a.x;
+    if (a.y > m) { m = a.y; arg = 1; }
+    if (b.x > m) { m = b.x; arg = 2; }
+    if (b.y > m) { m = b.y; arg = 3; }
+    float2 oa, ob;
+    oa.x = arg == 0 ? g : 0.f;
+    oa.y = arg == 1 ? g : 0.f;
+    ob.x = arg == 2 ? g : 0.f;
+    ob.y = arg == 3 ? g : 0.f;
+    *reinterpret_cast<float2*>(dx + base) = oa;
+    *reinterpret_cast<float2*>(dx + base + Wi) = ob;
+}
+
+int check_plane(int BC, int Hi, int Wi, int Ho, int Wo, const char* who) {
+    if (!(BC > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Ho <= 65535 && Hi <= 65535 && BC <= 65535 * 32)) {
+        gd_set_error(who);
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// blockIdx.z is limited to 65535: split BC over several launches when needed
+#define GD_FOR_BC_SLICES(BC, body)                        \
+    for (long z0_ = 0; z0_ < (BC); z0_ += 65535) {        \
+        const int nz_ = (int)(((BC) - z0_) < 65535 ? ((BC) - z0_) : 65535); \
+        body                                              \
+    }
+
+extern "C" int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, float rsh, float rsw,
+                              void* stream) {
+    GD_CHECK_ARG(x && y, "gd_bicubic_fwd: null pointer");
+    if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bicubic_fwd: bad sizes")) return -1;
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bicubic_fwd_kernel, dim3(gd_cdiv(Wo, 256), Ho, nz_), dim3(256), 0,
+                                            (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
+                                            y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, float rsh, float rsw,
+                              void* stream) {
+    GD_CHECK_ARG(dy && dx, "gd_bicubic_bwd: null pointer");
+    if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bicubic_bwd: bad sizes")) return -1;
+    GD_CHECK_ARG(4.f / rsw + 5.f <= (float)WMAX, "gd_bicubic_bwd: scale factor too large for the gather window");
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL((resize_bwd_gather_kernel<true>), dim3(gd_cdiv(Wi, 256), Hi, nz_), dim3(256),
+                                            0, (hipStream_t)stream, dy + z0_ * (long)Ho * Wo, Hi, Wi,
+                                            dx + z0_ * (long)Hi * Wi, Ho, Wo, rsh, rsw);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate,
+                               void* stream) {
+    GD_CHECK_ARG(x && y, "gd_bilinear_fwd: null pointer");
+    if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bilinear_fwd: bad sizes")) return -1;
+    const float rsh = (float)Hi / (float)Ho, rsw = (float)Wi / (float)Wo;
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(gd_cdiv(Wo, 256), Ho, nz_), dim3(256), 0,
+                                            (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
+                                            y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw, accumulate);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_bilinear_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, void* stream) {
+    GD_CHECK_ARG(dy && dx, "gd_bilinear_bwd: null pointer");
+    if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bilinear_bwd: bad sizes")) return -1;
+    const float rsh = (float)Hi / (float)Ho, rsw = (float)Wi / (float)Wo;
+    GD_CHECK_ARG(2.f / rsw + 5.f <= (float)WMAX, "gd_bilinear_bwd: scale factor too large for the gather window");
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL((resize_bwd_gather_kernel<false>), dim3(gd_cdiv(Wi, 256), Hi, nz_), dim3(256),
+                                            0, (hipStream_t)stream, dy + z0_ * (long)Ho * Wo, Hi, Wi,
+                                            dx + z0_ * (long)Hi * Wi, Ho, Wo, rsh, rsw);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_maxpool2_fwd(const float* x, int BC, int Hi, int Wi, float* y, void* stream) {
+    GD_CHECK_ARG(x && y, "gd_maxpool2_fwd: null pointer");
+    GD_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0, "gd_maxpool2_fwd: odd sizes unsupported");
+    if (check_plane(BC, Hi, Wi, Hi / 2, Wi / 2, "gd_maxpool2_fwd: bad sizes")) return -1;
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(gd_cdiv(Wi / 2, 256), Hi / 2, nz_), dim3(256), 0,
+                                            (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
+                                            y + z0_ * (long)(Hi / 2) * (Wi / 2));)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_maxpool2_bwd(const float* x, const float* dy, int BC, int Hi, int Wi, float* dx, void* stream) {
+    GD_CHECK_ARG(x && dy && dx, "gd_maxpool2_bwd: null pointer");
+    GD_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0, "gd_maxpool2_bwd: odd sizes unsupported");
+    if (check_plane(BC, Hi, Wi, Hi / 2, Wi / 2, "gd_maxpool2_bwd: bad sizes")) return -1;
+    GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(gd_cdiv(Wi / 2, 256), Hi / 2, nz_), dim3(256), 0,
+                                            (hipStream_t)stream, x + z0_ * (long)Hi * Wi,
+                                            dy + z0_ * (long)(Hi / 2) * (Wi / 2), Hi, Wi, dx + z0_ * (long)Hi * Wi);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,222 @@
+"""GAN-DANet generator on HIP kernels: the reference's module tree (class names, constructor signatures,
+attribute names == ``state_dict`` keys of models/generator.py) with MI355X-first forwards:
+
+* DenseBlock        one autograd node over a pre-allocated channel slab (no torch.cat); each layer's
+                    BatchNorm+ReLU is folded into its conv's operand load           (generator.py:29-54)
+* DANetAttention    PAM (fused flash attention, bf16 MFMA) and CAM (split-K Gram + row softmax + apply)
+                    write the two halves of one 2C buffer, then conv3x3+BN+ReLU     (generator.py:104-157)
+* TransitionLayer   BN+ReLU folded into the 1x1 conv                              (generator.py:57-67)
+* skip connections  the bias-free 1x1 ``channel_adjust`` convs commute with the bilinear resize, so they
+                    run at H x W instead of 4H x 4W and the three skips share one upsample-add
+                                                                                    (generator.py:243-245)
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .layers import ACT_RELU, BatchNorm2d, Conv2d, ReLU, UpsampleBicubic2x
+
+
+class _ConvBnRelu(nn.Sequential):
+    """[Conv2d, BatchNorm2d, ReLU] with the reference's indices; BN+ReLU run as one kernel."""
+
+    def __init__(self, cin: int, cout: int, k: int, pad: int) -> None:
+        super().__init__(Conv2d(cin, cout, kernel_size=k, padding=pad, bias=False), BatchNorm2d(cout), ReLU())
+
+    def forward(self, x):
+        return self[1](self[0](x), ACT_RELU)
+
+
+class DenseLayer(nn.Module):
+    def __init__(self, in_channels: int, growth_rate: int) -> None:
+        super().__init__()
+        self.bn = BatchNorm2d(in_channels)
+        self.relu = ReLU()
+        self.conv = Conv2d(in_channels, growth_rate, kernel_size=3, padding=1)
+
+    def forward(self, x):  # stand-alone use; inside DenseBlock the slab path below is taken
+        return DenseBlock.run([self], x)
+
+
+class DenseBlock(nn.Module):
+    def __init__(self, num_layers: int, in_channels: int, growth_rate: int) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList(
+            DenseLayer(in_channels + i * growth_rate, growth_rate) for i in range(num_layers))
+
+    @staticmethod
+    def run(layers, x):
+        flat = []
+        training = momentum = eps = None
+        for lyr in layers:
+            g, b, rm, rv, training, momentum, eps = lyr.bn.fold_args()
+            flat += [g, b, rm, rv, lyr.conv.weight, lyr.conv.bias]
+        return ops.DenseBlockFn.apply(x, training, momentum, eps, *flat)
+
+    def forward(self, x):
+        return DenseBlock.run(list(self.layers), x)
+
+
+class TransitionLayer(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int) -> None:
+        super().__init__()
+        self.layer = nn.Sequential(BatchNorm2d(in_channels), ReLU(), Conv2d(in_channels, out_channels, kernel_size=1))
+
+    def forward(self, x):
+        g, b, rm, rv, training, momentum, eps = self.layer[0].fold_args()
+        conv = self.layer[2]
+        return ops.BnReluConvFn.apply(x, g, b, rm, rv, conv.weight, conv.bias, training, momentum, eps, 0)
+
+
+class PAMModule(nn.Module):
+    """Position attention (generator.py:104-122).  """
+
+    def __init__(self, channels: int) -> None:
+        super().__init__()
+        r = max(1, channels // 8)
+        self.query = Conv2d(channels, r, kernel_size=1)
+        self.key = Conv2d(channels, r, kernel_size=1)
+        self.value = Conv2d(channels, channels, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return ops.PamFn.apply(x, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                               self.value.weight, self.value.bias, self.gamma)
+
+
+class CAMModule(nn.Module):
+    """Channel attention (generator.py:125-139); ``channels`` is unused there as well."""
+
+    def __init__(self, channels: int) -> None:
+        super().__init__()
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return ops.CamFn.apply(x, self.gamma)
+
+
+class DANetAttention(nn.Module):
+    def __init__(self, channels: int) -> None:
+        super().__init__()
+        self.position_attention = PAMModule(channels)
+        self.channel_attention = CAMModule(channels)
+        self.fuse = _ConvBnRelu(2 * channels, channels, 3, 1)
+
+    def forward(self, x):
+        pa = self.position_attention
+        feats = ops.DualAttentionFn.apply(x, pa.query.weight, pa.query.bias, pa.key.weight, pa.key.bias,
+                                          pa.value.weight, pa.value.bias, pa.gamma, self.channel_attention.gamma)
+        return self.fuse(feats)
+
+
+def _build_attention(attention_type: Optional[str], channels: int) -> Optional[nn.Module]:
+    """generator.py:160-172.  'senet'/'cbam' alias to 'danet' (the reference raises NameError there because
+    ``warnings`` is never imported; the aliasing it intends is kept)."""
+    if attention_type is None or attention_type.lower() == "none":
+        return None
+    kind = attention_type.lower()
+    if kind in ("senet", "cbam"):
+        warnings.warn(f"Attention type '{attention_type}' currently aliases to 'danet'.", RuntimeWarning)
+    elif kind != "danet":
+        raise ValueError(f"Unsupported attention type: {attention_type}")
+    return DANetAttention(channels)
+
+
+class FlexibleUpsamplingModule(nn.Module):
+    """Super-resolution generator (x4) of GAN-DANet (generator.py:175-247)."""
+
+    def __init__(self, input_channels: int = 40, growth_rate: int = 24, num_blocks: int = 3,
+                 num_layers_per_block: int = 4, attention_type: Optional[str] = "danet") -> None:
+        super().__init__()
+        self.initial = _ConvBnRelu(input_channels, 64, 3, 1)
+        self.dense_blocks = nn.ModuleList()
+        self.transition_layers = nn.ModuleList()
+        self.attention_modules = nn.ModuleList()
+        self.feature_channels: List[int] = []
+        width = 64
+        for i in range(num_blocks):
+            self.dense_blocks.append(DenseBlock(num_layers_per_block, width, growth_rate))
+            width += num_layers_per_block * growth_rate
+            self.attention_modules.append(_build_attention(attention_type, width))
+            self.feature_channels.append(width)
+            if i + 1 < num_blocks:
+                self.transition_layers.append(TransitionLayer(width, width // 2))
+                width //= 2
+        self.channel_adjust = nn.ModuleList(
+            Conv2d(ch, 64, kernel_size=1, bias=False) for ch in self.feature_channels[::-1])
+        self.upsample = nn.Sequential(
+            Conv2d(width, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), ReLU(), UpsampleBicubic2x(),
+            Conv2d(64, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), ReLU(), UpsampleBicubic2x())
+        self.final = Conv2d(64, 1, kernel_size=3, padding=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.initial(x)
+        skips = []
+        for i, block in enumerate(self.dense_blocks):
+            x = block(x)
+            att = self.attention_modules[i]
+            if att is not None:
+                x = att(x)
+            skips.append(x)
+            if i < len(self.transition_layers):
+                x = self.transition_layers[i](x)
+        up = self.upsample
+        x = up[3](up[1](up[0](x), ACT_RELU))
+        x = up[7](up[5](up[4](x), ACT_RELU))
+        x = ops.SkipFuseFn.apply(x, *[adj.weight for adj in self.channel_adjust], *skips[::-1])
+        return self.final(x)
+
+
+# ---- exported by the reference but not used by the train loop: compositions of the same kernels --------
+class OriginalRelationshipLearner(nn.Module):
+    """generator.py:11-26: five conv3x3+ReLU."""
+
+    def __init__(self, input_channels: int) -> None:
+        super().__init__()
+        mods, cin = [], input_channels
+        for cout in (64, 128, 256, 512, 1024):
+            mods += [Conv2d(cin, cout, kernel_size=3, padding=1), ReLU()]
+            cin = cout
+        self.net = nn.Sequential(*mods)
+
+    def forward(self, x):
+        for i in range(0, len(self.net), 2):
+            x = self.net[i](x, ACT_RELU)
+        return x
+
+
+class SqueezeExcitation(nn.Module):
+    """generator.py:70-84 -- API parity only: not on the training path, not implemented on the HIP path yet."""
+
+    def __init__(self, channels: int, reduction_ratio: int = 16) -> None:
+        super().__init__()
+        red = max(1, channels // reduction_ratio)
+        self.avg_pool = nn.Identity()
+        self.fc1 = Conv2d(channels, red, kernel_size=1)
+        self.relu = ReLU()
+        self.fc2 = Conv2d(red, channels, kernel_size=1)
+        self.sigmoid = nn.Identity()
+
+    def forward(self, x):
+        raise NotImplementedError("SqueezeExcitation is exported for API parity; it is outside the G+D hot path "
+                                  "(SURVEY.md section 8 a14) and has no HIP kernels yet")
+
+
+class CBAMBlock(nn.Module):
+    """generator.py:87-101 -- API parity only (see SqueezeExcitation)."""
+
+    def __init__(self, channels: int, reduction_ratio: int = 16) -> None:
+        super().__init__()
+        self.channel_attention = SqueezeExcitation(channels, reduction_ratio)
+        self.spatial_attention = nn.Sequential(nn.Conv2d(2, 1, kernel_size=7, padding=3, bias=False), nn.Identity())
+
+    def forward(self, x):
+        raise NotImplementedError("CBAMBlock is exported for API parity; it is outside the G+D hot path")
+
+
+__all__ = ["OriginalRelationshipLearner", "FlexibleUpsamplingModule", "SqueezeExcitation", "CBAMBlock"]

@@ -1,0 +1,475 @@
+"""Tensor-level wrappers of the C ABI (no autograd here).
+
+torch is used for device memory and streams only: every function takes CUDA
+(ROCm) fp32 tensors, checks layout on the host, allocates outputs/workspaces
+with ``torch.empty`` and enqueues the HIP kernels on torch's current stream.
+CPU tensors are rejected -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, name: str = "tensor", dtype=torch.float32) -> None:
+    if not t.is_cuda:
+        raise L.GandanetError(f"{name}: expected a GPU tensor (there is no CPU fallback in the product path)")
+    if t.dtype != dtype:
+        raise L.GandanetError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _dense(t: Tensor, name: str = "tensor") -> Tensor:
+    _chk(t, name)
+    if not t.is_contiguous():
+        raise L.GandanetError(f"{name}: expected a contiguous tensor, got strides {t.stride()}")
+    return t
+
+
+def _bview(t: Tensor, name: str = "tensor") -> int:
+    """Validate a (B, C, H, W) or (B, C, N) tensor whose per-image block is dense (a channel slice of a
+    wider slab is fine) and return its batch stride in elements."""
+    _chk(t, name)
+    if t.dim() == 4:
+        b, c, h, w = t.shape
+        ok = t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w
+        inner = c * h * w
+    elif t.dim() == 3:
+        b, c, n = t.shape
+        ok = t.stride(2) == 1 and t.stride(1) == n
+        inner = c * n
+    else:
+        raise L.GandanetError(f"{name}: expected a 3-D or 4-D tensor")
+    if not ok:
+        raise L.GandanetError(f"{name}: per-image block must be dense, got strides {t.stride()}")
+    bs = t.stride(0) if b > 1 else inner
+    if b > 1 and bs < inner:
+        raise L.GandanetError(f"{name}: overlapping batch stride")
+    return bs
+
+
+def lib():
+    return L.load()
+
+
+# ------------------------------------------------------------------------------------------------
+# implicit-GEMM "NN" kernel
+# ------------------------------------------------------------------------------------------------
+def conv_nn(*, B: int, M: int, Ck: int, ks: int, stride: int, pad: int, transposed: bool, Hi: int, Wi: int,
+            Ho: int, Wo: int, a: Tensor, a_bs: int, a_sm: int, a_sc: int, a_st: int, x: Tensor, x_bs: int,
+            y: Tensor, y_bs: int, precision: int, Mstore: int = 0, in_scale: Optional[Tensor] = None,
+            in_shift: Optional[Tensor] = None, in_relu: bool = False, out_layout: int = 0, out_bf16: bool = False,
+            ldo: int = 0, alpha: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+            res: Optional[Tensor] = None, res_bs: int = 0, act: int = 0, accumulate: bool = False) -> None:
+    d = L.ConvDesc()
+    d.B, d.M, d.Mstore, d.Ck, d.ks, d.stride, d.pad = B, M, max(M, Mstore), Ck, ks, stride, pad
+    d.transposed = int(transposed)
+    d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
+    d.a, d.a_bs, d.a_sm, d.a_sc, d.a_st = _ptr(a), a_bs, a_sm, a_sc, a_st
+    d.x, d.x_bs = _ptr(x), x_bs
+    d.in_scale, d.in_shift, d.in_relu = _ptr(in_scale), _ptr(in_shift), int(in_relu)
+    d.y, d.y_bs = _ptr(y), y_bs
+    d.out_layout, d.out_bf16, d.ldo = out_layout, int(out_bf16), ldo
+    d.alpha, d.bias, d.res, d.res_bs = _ptr(alpha), _ptr(bias), _ptr(res), res_bs
+    d.act, d.accumulate, d.precision = act, int(accumulate), precision
+    L.check(lib().gd_conv2d(C.byref(d), _stream()), "gd_conv2d")
+
+
+def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: int, precision: int, *,
+               act: int = 0, out: Optional[Tensor] = None, in_scale=None, in_shift=None, in_relu=False,
+               accumulate: bool = False) -> Tensor:
+    """nn.Conv2d forward, optional fused input affine+ReLU, bias, activation; ``out`` may be a channel slice."""
+    xbs = _bview(x, "conv input")
+    _dense(w, "conv weight")
+    B, Cin, Hi, Wi = x.shape
+    Cout, Cin_w, k, k2 = w.shape
+    if Cin_w != Cin or k != k2:
+        raise L.GandanetError(f"conv2d: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    Ho, Wo = conv_out_size(Hi, k, stride, pad), conv_out_size(Wi, k, stride, pad)
+    if out is None:
+        out = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, Cout, Ho, Wo):
+        raise L.GandanetError("conv2d: bad out shape")
+    conv_nn(B=B, M=Cout, Ck=Cin, ks=k, stride=stride, pad=pad, transposed=False, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo,
+            a=w, a_bs=0, a_sm=Cin * k * k, a_sc=k * k, a_st=1, x=x, x_bs=xbs, y=out, y_bs=_bview(out, "conv out"),
+            precision=precision, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, bias=bias, act=act,
+            accumulate=accumulate)
+    return out
+
+
+def conv2d_dgrad(dy: Tensor, w: Tensor, in_hw: Tuple[int, int], stride: int, pad: int, precision: int, *,
+                 out: Optional[Tensor] = None, accumulate: bool = False, alpha: Optional[Tensor] = None) -> Tensor:
+    """Gradient of nn.Conv2d w.r.t. its input: transposed gather of dy with the same OIHW weights."""
+    dbs = _bview(dy, "conv dy")
+    B, Cout, Ho, Wo = dy.shape
+    Cout_w, Cin, k, _ = w.shape
+    Hi, Wi = in_hw
+    if Cout_w != Cout:
+        raise L.GandanetError("conv2d_dgrad: weight/out-channel mismatch")
+    if out is None:
+        out = torch.empty(B, Cin, Hi, Wi, device=dy.device, dtype=torch.float32)
+    conv_nn(B=B, M=Cin, Ck=Cout, ks=k, stride=stride, pad=pad, transposed=True, Hi=Ho, Wi=Wo, Ho=Hi, Wo=Wi,
+            a=w, a_bs=0, a_sm=k * k, a_sc=Cin * k * k, a_st=1, x=dy, x_bs=dbs, y=out, y_bs=_bview(out, "conv dx"),
+            precision=precision, accumulate=accumulate, alpha=alpha)
+    return out
+
+
+def gemm_nt(*, B: int, M: int, N: int, kseg: int, klen: int, a: Tensor, a_bs: int, a_ss: int, lda: int,
+            bm: Tensor, b_bs: int, b_ss: int, ldb: int, c: Tensor, c_bs: int, ldc: int, precision: int,
+            im2col=None, in_scale=None, in_shift=None, in_relu=False, alpha=None, bias=None,
+            accumulate: bool = False, splits: int = 0) -> None:
+    d = L.GemmNTDesc()
+    d.B, d.M, d.N, d.kseg, d.klen = B, M, N, kseg, klen
+    d.a, d.a_bs, d.a_ss, d.lda = _ptr(a), a_bs, a_ss, lda
+    d.bm, d.b_bs, d.b_ss, d.ldb = _ptr(bm), b_bs, b_ss, ldb
+    if im2col is not None:
+        d.im2col = 1
+        d.ks, d.stride, d.pad, d.Hi, d.Wi, d.Ho, d.Wo = im2col
+    d.in_scale, d.in_shift, d.in_relu = _ptr(in_scale), _ptr(in_shift), int(in_relu)
+    d.c, d.c_bs, d.ldc = _ptr(c), c_bs, ldc
+    d.alpha, d.bias = _ptr(alpha), _ptr(bias)
+    d.accumulate, d.splits, d.precision = int(accumulate), splits, precision
+    L.check(lib().gd_gemm_nt(C.byref(d), _stream()), "gd_gemm_nt")
+
+
+def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision: int, *, in_scale=None,
+                 in_shift=None, in_relu=False) -> Tensor:
+    """Gradient of nn.Conv2d w.r.t. its OIHW weight: dW[co][ci,kh,kw] = sum_{b,p} dy[b,co,p] x~[b,ci,p(+)tap]."""
+    dbs, xbs = _bview(dy, "wgrad dy"), _bview(x, "wgrad x")
+    B, Cout, Ho, Wo = dy.shape
+    _, Cin, Hi, Wi = x.shape
+    dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
+    gemm_nt(B=1, M=Cout, N=Cin * k * k, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0,
+            b_ss=xbs, ldb=0, c=dw, c_bs=0, ldc=Cin * k * k, precision=precision,
+            im2col=(k, stride, pad, Hi, Wi, Ho, Wo), in_scale=in_scale, in_shift=in_shift, in_relu=in_relu)
+    return dw
+
+
+def bn_ws(B: int, Cn: int, HW: int, device) -> Tensor:
+    n = lib().gd_bn_stats_ws_floats(B, Cn, HW)
+    return torch.empty(max(int(n), 1), device=device, dtype=torch.float32)
+
+
+def channel_sum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    bs = _bview(x, "channel_sum input")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if out is None:
+        out = torch.empty(Cn, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_channel_sum(_ptr(x), bs, B, Cn, HW, _ptr(out), int(accumulate), _ptr(bn_ws(B, Cn, HW, x.device)),
+                                 _stream()), "gd_channel_sum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------------
+def bn_stats(x: Tensor, eps: float, momentum: float, running_mean: Optional[Tensor],
+             running_var: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    bs = _bview(x, "bn input")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    mean = torch.empty(Cn, device=x.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    L.check(lib().gd_bn_stats(_ptr(x), bs, B, Cn, HW, eps, momentum, _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                              _ptr(running_var), _ptr(bn_ws(B, Cn, HW, x.device)), _stream()), "gd_bn_stats")
+    return mean, invstd
+
+
+def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, invstd: Tensor) -> Tuple[Tensor, Tensor]:
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    L.check(lib().gd_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), gamma.numel(), _ptr(scale),
+                             _ptr(shift), _stream()), "gd_bn_fold")
+    return scale, shift
+
+
+def bn_fold_eval(gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, eps: float):
+    scale, shift, invstd = torch.empty_like(gamma), torch.empty_like(gamma), torch.empty_like(gamma)
+    L.check(lib().gd_bn_fold_eval(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
+                                  gamma.numel(), _ptr(scale), _ptr(shift), _ptr(invstd), _stream()), "gd_bn_fold_eval")
+    return scale, shift, invstd
+
+
+def affine_act(x: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], act: int,
+               out: Optional[Tensor] = None) -> Tensor:
+    bs = _bview(x, "affine input")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_affine_act(_ptr(x), bs, _ptr(scale), _ptr(shift), B, Cn, HW, act, _ptr(out), _bview(out),
+                                _stream()), "gd_affine_act")
+    return out
+
+
+def bn_act_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, act: int,
+               train: bool, dx: Optional[Tensor] = None, accumulate_dx: bool = False, want_dx: bool = True):
+    dbs, xbs = _bview(dy, "bn dy"), _bview(x, "bn x")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    dgamma = torch.empty(Cn, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    if want_dx and dx is None:
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_bn_act_bwd(_ptr(dy), dbs, _ptr(x), xbs, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), None,
+                                B, Cn, HW, act, int(train), _ptr(dgamma), _ptr(dbeta), _ptr(dx) if want_dx else None,
+                                _bview(dx) if want_dx else 0, int(accumulate_dx), _ptr(bn_ws(B, Cn, HW, x.device)),
+                                _stream()), "gd_bn_act_bwd")
+    return dgamma, dbeta, dx
+
+
+# ------------------------------------------------------------------------------------------------
+# resampling
+# ------------------------------------------------------------------------------------------------
+def bicubic_fwd(x: Tensor, Ho: int, Wo: int, rsh: float, rsw: float) -> Tensor:
+    _dense(x, "bicubic input")
+    B, Cn, Hi, Wi = x.shape
+    y = torch.empty(B, Cn, Ho, Wo, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_bicubic_fwd(_ptr(x), B * Cn, Hi, Wi, _ptr(y), Ho, Wo, rsh, rsw, _stream()), "gd_bicubic_fwd")
+    return y
+
+
+def bicubic_bwd(dy: Tensor, Hi: int, Wi: int, rsh: float, rsw: float) -> Tensor:
+    _dense(dy, "bicubic dy")
+    B, Cn, Ho, Wo = dy.shape
+    dx = torch.empty(B, Cn, Hi, Wi, device=dy.device, dtype=torch.float32)
+    L.check(lib().gd_bicubic_bwd(_ptr(dy), B * Cn, Hi, Wi, _ptr(dx), Ho, Wo, rsh, rsw, _stream()), "gd_bicubic_bwd")
+    return dx
+
+
+def bilinear_fwd(x: Tensor, Ho: int, Wo: int, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _dense(x, "bilinear input")
+    B, Cn, Hi, Wi = x.shape
+    if out is None:
+        out = torch.empty(B, Cn, Ho, Wo, device=x.device, dtype=torch.float32)
+        accumulate = False
+    _dense(out, "bilinear out")
+    L.check(lib().gd_bilinear_fwd(_ptr(x), B * Cn, Hi, Wi, _ptr(out), Ho, Wo, int(accumulate), _stream()),
+            "gd_bilinear_fwd")
+    return out
+
+
+def bilinear_bwd(dy: Tensor, Hi: int, Wi: int) -> Tensor:
+    _dense(dy, "bilinear dy")
+    B, Cn, Ho, Wo = dy.shape
+    dx = torch.empty(B, Cn, Hi, Wi, device=dy.device, dtype=torch.float32)
+    L.check(lib().gd_bilinear_bwd(_ptr(dy), B * Cn, Hi, Wi, _ptr(dx), Ho, Wo, _stream()), "gd_bilinear_bwd")
+    return dx
+
+
+def maxpool2_fwd(x: Tensor) -> Tensor:
+    _dense(x, "maxpool input")
+    B, Cn, Hi, Wi = x.shape
+    y = torch.empty(B, Cn, Hi // 2, Wi // 2, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_maxpool2_fwd(_ptr(x), B * Cn, Hi, Wi, _ptr(y), _stream()), "gd_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x: Tensor, dy: Tensor) -> Tensor:
+    _dense(x), _dense(dy)
+    B, Cn, Hi, Wi = x.shape
+    dx = torch.empty_like(x)
+    L.check(lib().gd_maxpool2_bwd(_ptr(x), _ptr(dy), B * Cn, Hi, Wi, _ptr(dx), _stream()), "gd_maxpool2_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# pointwise / reductions
+# ------------------------------------------------------------------------------------------------
+def act_fwd(x: Tensor, act: int, out: Optional[Tensor] = None) -> Tensor:
+    _dense(x)
+    out = torch.empty_like(x) if out is None else out
+    L.check(lib().gd_act_fwd(_ptr(x), _ptr(out), x.numel(), act, _stream()), "gd_act_fwd")
+    return out
+
+
+def act_bwd(y: Tensor, dy: Tensor, act: int) -> Tensor:
+    _dense(y), _dense(dy)
+    dx = torch.empty_like(dy)
+    L.check(lib().gd_act_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), act, _stream()), "gd_act_bwd")
+    return dx
+
+
+def axpby(x: Tensor, a: float, y: Tensor, b: float) -> Tensor:
+    """y = a*x + b*y (in place on y)"""
+    _dense(x), _dense(y)
+    L.check(lib().gd_axpby(_ptr(x), a, _ptr(y), b, x.numel(), _stream()), "gd_axpby")
+    return y
+
+
+def scale_dev(x: Tensor, s: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """out (+)= s * x with s a 1-element device tensor"""
+    _dense(x)
+    if out is None:
+        out = torch.empty_like(x)
+        accumulate = False
+    L.check(lib().gd_scale_dev(_ptr(x), _ptr(s), _ptr(out), x.numel(), int(accumulate), _stream()), "gd_scale_dev")
+    return out
+
+
+def copy_slab(src: Tensor, dst: Tensor, accumulate: bool = False) -> Tensor:
+    sbs, dbs = _bview(src, "copy src"), _bview(dst, "copy dst")
+    if src.shape != dst.shape:
+        raise L.GandanetError("copy_slab: shape mismatch")
+    L.check(lib().gd_copy_slab(_ptr(src), sbs, _ptr(dst), dbs, src.shape[0], src[0].numel(), int(accumulate),
+                               _stream()), "gd_copy_slab")
+    return dst
+
+
+def softmax_rows(x: Tensor, sign: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    _dense(x)
+    out = torch.empty_like(x) if out is None else out
+    cols = x.shape[-1]
+    L.check(lib().gd_softmax_rows(_ptr(x), _ptr(out), x.numel() // cols, cols, sign, _stream()), "gd_softmax_rows")
+    return out
+
+
+def softmax_rows_bwd(p: Tensor, dp: Tensor, sign: float = 1.0) -> Tensor:
+    _dense(p), _dense(dp)
+    dx = torch.empty_like(p)
+    cols = p.shape[-1]
+    L.check(lib().gd_softmax_rows_bwd(_ptr(p), _ptr(dp), _ptr(dx), p.numel() // cols, cols, sign, _stream()),
+            "gd_softmax_rows_bwd")
+    return dx
+
+
+def _red_ws(device) -> Tensor:
+    return torch.empty(2048, device=device, dtype=torch.float32)
+
+
+def dot(a: Tensor, b: Optional[Tensor], out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _dense(a)
+    if b is not None:
+        _dense(b)
+    if out is None:
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        accumulate = False
+    L.check(lib().gd_dot(_ptr(a), _ptr(b), a.numel(), _ptr(out), int(accumulate), _ptr(_red_ws(a.device)), _stream()),
+            "gd_dot")
+    return out
+
+
+def transpose(s: Tensor) -> Tensor:
+    """(B, R, C) -> (B, C, R)"""
+    _dense(s)
+    B, R, Cc = s.shape
+    t = torch.empty(B, Cc, R, device=s.device, dtype=torch.float32)
+    L.check(lib().gd_transpose(_ptr(s), _ptr(t), B, R, Cc, _stream()), "gd_transpose")
+    return t
+
+
+def add_transpose(a: Tensor) -> Tensor:
+    _dense(a)
+    B, n, _ = a.shape
+    out = torch.empty_like(a)
+    L.check(lib().gd_add_transpose(_ptr(a), _ptr(out), B, n, _stream()), "gd_add_transpose")
+    return out
+
+
+def copy_rows(src: Tensor, s_bs: int, s_ld: int, dst: Tensor, d_bs: int, d_ld: int, B: int, R: int, Cc: int):
+    L.check(lib().gd_copy_rows(_ptr(src), s_bs, s_ld, _ptr(dst), d_bs, d_ld, B, R, Cc, _stream()), "gd_copy_rows")
+    return dst
+
+
+# ---- losses ---------------------------------------------------------------------------------------
+def bce_logits(z: Tensor, label: float, want_grad: bool):
+    _dense(z)
+    out = torch.empty(1, device=z.device, dtype=torch.float32)
+    dz = torch.empty_like(z) if want_grad else None
+    L.check(lib().gd_bce_logits(_ptr(z), z.numel(), label, _ptr(out), _ptr(dz), _ptr(_red_ws(z.device)), _stream()),
+            "gd_bce_logits")
+    return out, dz
+
+
+def diff_loss(kind: str, a: Tensor, b: Tensor, want_grad: bool):
+    _dense(a), _dense(b)
+    if a.shape != b.shape:
+        raise L.GandanetError(f"{kind}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    da = torch.empty_like(a) if want_grad else None
+    fn = lib().gd_mse if kind == "mse" else lib().gd_l1
+    L.check(fn(_ptr(a), _ptr(b), a.numel(), _ptr(out), _ptr(da), _ptr(_red_ws(a.device)), _stream()), f"gd_{kind}")
+    return out, da
+
+
+def tv(x: Tensor, weight: float, want_grad: bool):
+    _dense(x)
+    B, Cn, H, W = x.shape
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if want_grad else None
+    L.check(lib().gd_tv(_ptr(x), B, Cn, H, W, weight, _ptr(out), _ptr(dx), _ptr(_red_ws(x.device)), _stream()), "gd_tv")
+    return out, dx
+
+
+def ssim(a: Tensor, b: Tensor, window: int) -> Tensor:
+    _dense(a), _dense(b)
+    B, Cn, H, W = a.shape
+    out = torch.empty(1, device=a.device, dtype=torch.float32)
+    L.check(lib().gd_ssim(_ptr(a), _ptr(b), B * Cn, H, W, window, _ptr(out), _ptr(_red_ws(a.device)), _stream()),
+            "gd_ssim")
+    return out
+
+
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, grad_scale: float = 1.0) -> None:
+    for t in (p, g, m, v):
+        _dense(t, "adamw tensor")
+    L.check(lib().gd_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps, weight_decay,
+                           grad_scale, _stream()), "gd_adamw")
+
+
+# ---- PAM helpers ------------------------------------------------------------------------------------
+def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, plain_shape=None, t_shape=None):
+    """s: (B, R, Cc)-like fp32 block (per-image dense).  Returns (plain, transposed) bf16 tensors (or None)."""
+    sbs = _bview(s, "pack input")
+    B = s.shape[0]
+    plain = tr = None
+    rp = ldp = ccp = ldt = 0
+    if plain_shape is not None:
+        rp, ldp = plain_shape
+        plain = torch.empty(B, rp, ldp, device=s.device, dtype=torch.bfloat16)
+    if t_shape is not None:
+        ccp, ldt = t_shape
+        tr = torch.empty(B, ccp, ldt, device=s.device, dtype=torch.bfloat16)
+    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), _ptr(plain), rp, ldp, _ptr(tr), ccp, ldt, _stream()),
+            "gd_pack_bf16")
+    return plain, tr
+
+
+def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
+    abs_, obs = _bview(a), _bview(o)
+    B, Cn = a.shape[0], a.shape[1]
+    N = a[0, 0].numel()
+    d_raw = torch.empty(B, N, device=a.device, dtype=torch.float32)
+    delta = torch.empty_like(d_raw)
+    L.check(lib().gd_chan_dot(_ptr(a), abs_, _ptr(o), obs, B, Cn, N, _ptr(gamma), _ptr(d_raw), _ptr(delta), _stream()),
+            "gd_chan_dot")
+    return d_raw, delta
+
+
+def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse):
+    L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, _ptr(gamma), _ptr(x), _bview(x),
+                                   _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()), "gd_pam_flash_fwd")
+
+
+def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqt, dkn, dv):
+    L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(qn), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(don), _ptr(lse),
+                                   _ptr(delta), B, N, Npad, Cp, _ptr(dqt), _ptr(dkn), _ptr(dv), _stream()),
+            "gd_pam_flash_bwd")

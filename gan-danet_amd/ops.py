@@ -1,0 +1,753 @@
+"""Differentiable ops of the GAN-DANet hot path: ``torch.autograd.Function``s whose forward and
+backward are sequences of HIP kernels (``kern.py`` -> C ABI).  torch's autograd engine is only the
+tape; no ATen compute op runs on the product path.
+
+Precision: ``config.precision`` ("bf16" | "fp32") selects the MFMA operand type of every
+GEMM-shaped kernel (fp32 accumulate in both).  "fp32" is the bit-exact parity mode; in "bf16" mode
+PAM runs the fused flash kernels, in "fp32" mode it runs the unfused reference-shaped product chain
+(materialised N x N matrices, small N only).  CAM always runs in fp32 (its logits scale with N).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import kern as K
+from .config import config
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY02
+
+
+def _prec() -> int:
+    return L.PREC_BF16 if config.precision == "bf16" else L.PREC_FP32
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# =====================================================================================================
+# convolution (+ bias + activation)        nn.Conv2d  (generator.py / discriminator.py / VGG)
+# =====================================================================================================
+class Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride: int, pad: int, act: int):
+        prec = _prec()
+        y = K.conv2d_fwd(x, w, bias, stride, pad, prec, act=act)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, prec, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, prec, has_bias = ctx.cfg
+        dy = _c(dy)
+        if act != ACT_NONE:
+            dy = K.act_bwd(y, dy, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad, prec)
+        if ctx.needs_input_grad[1]:
+            dw = K.conv2d_wgrad(dy, x, w.shape[2], stride, pad, prec)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = K.channel_sum(dy)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE):
+    return Conv2dFn.apply(x, w, bias, stride, pad, act)
+
+
+class ActFn(Function):
+    """stand-alone ReLU / LeakyReLU(0.2) (used where the activation is not fused into a producer)"""
+
+    @staticmethod
+    def forward(ctx, x, act: int):
+        y = K.act_fwd(_c(x), act)
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.act_bwd(y, _c(dy), ctx.act), None
+
+
+def activation(x, act: int):
+    return ActFn.apply(x, act)
+
+
+# =====================================================================================================
+# BatchNorm2d (+ activation)               generator.py:32,61,149,189,219,223
+# =====================================================================================================
+def _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps):
+    """statistics (+ running update) and the folded affine; returns (scale, shift, mean, invstd)"""
+    if training:
+        mean, invstd = K.bn_stats(x, eps, momentum, rmean, rvar)
+        scale, shift = K.bn_fold(gamma, beta, mean, invstd)
+    else:
+        scale, shift, invstd = K.bn_fold_eval(gamma, beta, rmean, rvar, eps)
+        mean = rmean
+    return scale, shift, mean, invstd
+
+
+class BnActFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training: bool, momentum: float, eps: float, act: int):
+        scale, shift, mean, invstd = _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps)
+        y = K.affine_act(x, scale, shift, act)
+        ctx.save_for_backward(x, scale, shift, mean, invstd)
+        ctx.cfg = (act, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd = ctx.saved_tensors
+        act, training = ctx.cfg
+        dgamma, dbeta, dx = K.bn_act_bwd(_c(dy), x, scale, shift, mean, invstd, act, training)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum, eps, act=ACT_NONE):
+    return BnActFn.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, act)
+
+
+class BnReluConvFn(Function):
+    """conv(relu(bn(x))) with the BN affine + ReLU folded into the conv's operand load (no intermediate).
+    TransitionLayer (generator.py:57-67)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, w, bias, training, momentum, eps, pad):
+        prec = _prec()
+        scale, shift, mean, invstd = _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps)
+        y = K.conv2d_fwd(x, w, bias, 1, pad, prec, in_scale=scale, in_shift=shift, in_relu=True)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, w)
+        ctx.cfg = (training, prec, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd, w = ctx.saved_tensors
+        training, prec, pad, has_bias = ctx.cfg
+        dy = _c(dy)
+        dw = K.conv2d_wgrad(dy, x, w.shape[2], 1, pad, prec, in_scale=scale, in_shift=shift, in_relu=True)
+        db = K.channel_sum(dy) if has_bias else None
+        dxt = K.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), 1, pad, prec)
+        dgamma, dbeta, dx = K.bn_act_bwd(dxt, x, scale, shift, mean, invstd, ACT_RELU, training)
+        return dx, dgamma, dbeta, None, None, dw, db, None, None, None, None
+
+
+# =====================================================================================================
+# DenseBlock: cat-free slab                generator.py:29-54
+# =====================================================================================================
+class DenseBlockFn(Function):
+    """The whole block as one node: the output slab (B, C0 + L*g, H, W) is allocated once, the input is
+    copied into its first C0 channels and every layer's conv writes its g new channels in place -- no
+    torch.cat.  BN+ReLU of each layer is folded into that layer's conv operand load.
+    args: x, training, momentum, eps, then per layer (bn_w, bn_b, bn_rm, bn_rv, conv_w, conv_b)."""
+
+    @staticmethod
+    def forward(ctx, x, training: bool, momentum: float, eps: float, *params):
+        prec = _prec()
+        nl = len(params) // 6
+        B, C0, H, W = x.shape
+        g = params[4].shape[0]
+        slab = torch.empty(B, C0 + nl * g, H, W, device=x.device, dtype=torch.float32)
+        K.copy_slab(x, slab[:, :C0])
+        saved: List[torch.Tensor] = []
+        for l in range(nl):
+            bw, bb, rm, rv, cw, cb = params[6 * l: 6 * l + 6]
+            cl = C0 + l * g
+            xin = slab[:, :cl]
+            scale, shift, mean, invstd = _bn_prepare(xin, bw, bb, rm, rv, training, momentum, eps)
+            K.conv2d_fwd(xin, cw, cb, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True,
+                         out=slab[:, cl:cl + g])
+            saved += [scale, shift, mean, invstd, cw]
+        ctx.save_for_backward(slab, *saved)
+        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]])
+        return slab
+
+    @staticmethod
+    def backward(ctx, dslab_in):
+        slab, *saved = ctx.saved_tensors
+        nl, C0, g, training, prec, has_bias = ctx.cfg
+        B, _, H, W = slab.shape
+        dslab = torch.empty(slab.shape, device=slab.device, dtype=torch.float32)  # accumulated into below
+        K.copy_slab(_c(dslab_in), dslab)
+        grads: List[Optional[torch.Tensor]] = [None] * (6 * nl)
+        for l in reversed(range(nl)):
+            scale, shift, mean, invstd, cw = saved[5 * l: 5 * l + 5]
+            cl = C0 + l * g
+            xin = slab[:, :cl]
+            dy = dslab[:, cl:cl + g]
+            grads[6 * l + 4] = K.conv2d_wgrad(dy, xin, 3, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True)
+            if has_bias[l]:
+                grads[6 * l + 5] = K.channel_sum(dy)
+            dxt = K.conv2d_dgrad(dy, cw, (H, W), 1, 1, prec)
+            dgamma, dbeta, _ = K.bn_act_bwd(dxt, xin, scale, shift, mean, invstd, ACT_RELU, training,
+                                            dx=dslab[:, :cl], accumulate_dx=True)
+            grads[6 * l + 0], grads[6 * l + 1] = dgamma, dbeta
+        dx = torch.empty(B, C0, H, W, device=slab.device, dtype=torch.float32)
+        K.copy_slab(dslab[:, :C0], dx)
+        return (dx, None, None, None, *grads)
+
+
+# =====================================================================================================
+# dual attention: PAM || CAM into one 2C slab      generator.py:104-157
+# =====================================================================================================
+def _npad(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def _cp(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
+    """PAM into ``out3`` (B, C, N) view.  Returns (fused?, tensors to keep for backward)."""
+    B, Cn, H, W = x.shape
+    N = H * W
+    r = wq.shape[0]
+    x3 = x.view(B, Cn, N)
+    fused = prec == L.PREC_BF16 and Cn <= 192 and r <= 32
+    q = K.conv2d_fwd(x, wq, bq, 1, 0, prec).view(B, r, N)
+    k = K.conv2d_fwd(x, wk, bk, 1, 0, prec).view(B, r, N)
+    v = K.conv2d_fwd(x, wv, bv, 1, 0, prec).view(B, Cn, N)
+    if fused:
+        Np, Cp = _npad(N), _cp(Cn)
+        qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
+        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
+        vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp))
+        del q, k, v
+        o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
+        lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse)
+        return True, (qt, kt, qn, kn, vt, o_attn, lse)
+    qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)
+    s = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
+    K.gemm_nt(B=B, M=N, N=N, kseg=1, klen=r, a=qt_, a_bs=N * r, a_ss=0, lda=r, bm=kt_, b_bs=N * r, b_ss=0,
+              ldb=r, c=s, c_bs=N * N, ldc=N, precision=prec, splits=1)
+    p = K.softmax_rows(s, 1.0, out=s)
+    o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
+    K.gemm_nt(B=B, M=Cn, N=N, kseg=1, klen=N, a=v, a_bs=Cn * N, a_ss=0, lda=N, bm=p, b_bs=N * N, b_ss=0,
+              ldb=N, c=o_attn, c_bs=Cn * N, ldc=N, precision=prec, splits=1)
+    K.copy_slab(x3, out3)
+    _axpy_dev3(o_attn, gamma_p, out3)
+    return False, (qt_, kt_, v, p, o_attn)
+
+
+def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has_bias):
+    """d_pam: (B, C, N) view of dOut.  Accumulates the projection data-gradients into ``dx`` (B, C, N; the
+    residual term is added by the caller).  Returns (dwq, dbq, dwk, dbk, dwv, dbv, dgamma)."""
+    B, Cn, H, W = x.shape
+    N = H * W
+    r = wq.shape[0]
+    if fused:
+        qt, kt, qn, kn, vt, o_attn, lse = pam_saved
+        Np, Cp = _npad(N), _cp(Cn)
+        d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
+        dgamma_p = K.dot(d_raw, None)
+        don, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, plain_shape=(Cp, Np), t_shape=(Np, Cp))
+        dqt = torch.zeros(B, Np, 32, device=x.device, dtype=torch.float32)
+        dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
+        dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
+        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqt, dkn, dvp)
+        dqn = K.transpose(dqt)                                   # (B, 32, Np)
+        dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
+    else:
+        qt_, kt_, v, p, o_attn = pam_saved
+        dop = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
+        K.copy_slab(d_pam, dop)
+        dgamma_p = K.dot(dop, o_attn)
+        K.scale_dev(dop, gamma_p, out=dop)                       # gamma * dOut (in place)
+        dp = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
+        # dP[i][j] = sum_c dO'[c][i] V[c][j]
+        K.conv_nn(B=B, M=N, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=dop,
+                  a_bs=Cn * N, a_sm=1, a_sc=N, a_st=0, x=v, x_bs=Cn * N, y=dp, y_bs=N * N, precision=prec)
+        ds = K.softmax_rows_bwd(p, dp, 1.0)
+        del dp
+        # dV[c][j] = sum_i dO'[c][i] P[i][j]
+        dv = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
+        K.conv_nn(B=B, M=Cn, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=dop,
+                  a_bs=Cn * N, a_sm=N, a_sc=1, a_st=0, x=p, x_bs=N * N, y=dv, y_bs=Cn * N, precision=prec)
+        # dQt[i][d] = sum_j dS[i][j] Kt[j][d] ; dKt[j][d] = sum_i dS[i][j] Qt[i][d]
+        dqt = torch.empty(B, N, r, device=x.device, dtype=torch.float32)
+        dkt = torch.empty(B, N, r, device=x.device, dtype=torch.float32)
+        K.conv_nn(B=B, M=N, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=r, Ho=1, Wo=r, a=ds,
+                  a_bs=N * N, a_sm=N, a_sc=1, a_st=0, x=kt_, x_bs=N * r, y=dqt, y_bs=N * r, precision=prec)
+        K.conv_nn(B=B, M=N, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=r, Ho=1, Wo=r, a=ds,
+                  a_bs=N * N, a_sm=1, a_sc=N, a_st=0, x=qt_, x_bs=N * r, y=dkt, y_bs=N * r, precision=prec)
+        dq, dk = K.transpose(dqt), K.transpose(dkt)               # (B, r, N)
+    grads = []
+    for dy3, w, hb in ((dq, wq, has_bias[0]), (dk, wk, has_bias[1]), (dv, wv, has_bias[2])):
+        dy4 = dy3.view(B, dy3.shape[1], H, W)
+        grads.append(K.conv2d_wgrad(dy4, x, 1, 1, 0, prec))
+        grads.append(K.channel_sum(dy4) if hb else None)
+        K.conv2d_dgrad(dy4, w, (H, W), 1, 0, prec, out=dx.view(B, Cn, H, W), accumulate=True)
+    return (*grads, dgamma_p)
+
+
+def _cam_forward(x, gamma_c, out3):
+    """CAM into ``out3``; always fp32 MFMA: the logits scale with N, bf16 operands would scramble the softmax."""
+    B, Cn, H, W = x.shape
+    N = H * W
+    x3 = x.view(B, Cn, N)
+    e = torch.empty(B, Cn, Cn, device=x.device, dtype=torch.float32)
+    K.gemm_nt(B=B, M=Cn, N=Cn, kseg=1, klen=N, a=x3, a_bs=Cn * N, a_ss=0, lda=N, bm=x3, b_bs=Cn * N, b_ss=0,
+              ldb=N, c=e, c_bs=Cn * Cn, ldc=Cn, precision=L.PREC_FP32)
+    att = K.softmax_rows(e, -1.0, out=e)   # softmax(rowmax(E) - E) == softmax(-E)
+    K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=att,
+              a_bs=Cn * Cn, a_sm=Cn, a_sc=1, a_st=0, x=x3, x_bs=Cn * N, y=out3, y_bs=K._bview(out3),
+              precision=L.PREC_FP32, alpha=gamma_c, res=x3, res_bs=Cn * N)
+    return att
+
+
+def _cam_backward(att, x, gamma_c, d_cam, dx):
+    """accumulates gamma * (att^T dOut + (dE + dE^T) X) into dx (residual added by the caller); returns dgamma"""
+    B, Cn, H, W = x.shape
+    N = H * W
+    x3 = x.view(B, Cn, N)
+    d_bs = K._bview(d_cam)
+    da = torch.empty(B, Cn, Cn, device=x.device, dtype=torch.float32)
+    K.gemm_nt(B=B, M=Cn, N=Cn, kseg=1, klen=N, a=d_cam, a_bs=d_bs, a_ss=0, lda=N, bm=x3, b_bs=Cn * N, b_ss=0,
+              ldb=N, c=da, c_bs=Cn * Cn, ldc=Cn, precision=L.PREC_FP32)
+    dgamma_c = K.dot(att, da)
+    de = K.softmax_rows_bwd(att, da, -1.0)
+    sym = K.add_transpose(de)
+    K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=att,
+              a_bs=Cn * Cn, a_sm=1, a_sc=Cn, a_st=0, x=d_cam, x_bs=d_bs, y=dx, y_bs=Cn * N,
+              precision=L.PREC_FP32, alpha=gamma_c, accumulate=True)
+    K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=sym,
+              a_bs=Cn * Cn, a_sm=Cn, a_sc=1, a_st=0, x=x3, x_bs=Cn * N, y=dx, y_bs=Cn * N,
+              precision=L.PREC_FP32, alpha=gamma_c, accumulate=True)
+    return dgamma_c
+
+
+class PamFn(Function):
+    """PAMModule.forward (generator.py:113-122)"""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma_p):
+        x = _c(x)
+        prec = _prec()
+        out = torch.empty_like(x)
+        fused, saved = _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, _as3(out), prec)
+        ctx.save_for_backward(x, wq, wk, wv, gamma_p, *saved)
+        ctx.cfg = (prec, fused, (bq is not None, bk is not None, bv is not None))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wq, wk, wv, gamma_p, *saved = ctx.saved_tensors
+        prec, fused, has_bias = ctx.cfg
+        B, Cn, H, W = x.shape
+        d3 = _as3(_c(dout))
+        dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
+        K.copy_slab(d3, dx)
+        dwq, dbq, dwk, dbk, dwv, dbv, dg = _pam_backward(fused, saved, x, wq, wk, wv, gamma_p, d3, dx, prec, has_bias)
+        return dx.view(B, Cn, H, W), dwq, dbq, dwk, dbk, dwv, dbv, dg
+
+
+class CamFn(Function):
+    """CAMModule.forward (generator.py:130-139)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma_c):
+        x = _c(x)
+        out = torch.empty_like(x)
+        att = _cam_forward(x, gamma_c, _as3(out))
+        ctx.save_for_backward(x, gamma_c, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma_c, att = ctx.saved_tensors
+        B, Cn, H, W = x.shape
+        d3 = _as3(_c(dout))
+        dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
+        K.copy_slab(d3, dx)
+        dg = _cam_backward(att, x, gamma_c, d3, dx)
+        return dx.view(B, Cn, H, W), dg
+
+
+class DualAttentionFn(Function):
+    """features = cat([PAM(x), CAM(x)], 1) written as the two halves of one (B, 2C, H, W) buffer
+    (DANetAttention.forward, generator.py:153-156, without the cat)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma_p, gamma_c):
+        x = _c(x)
+        B, Cn, H, W = x.shape
+        prec = _prec()
+        feats = torch.empty(B, 2 * Cn, H, W, device=x.device, dtype=torch.float32)
+        fused, saved = _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, _as3(feats[:, :Cn]), prec)
+        att = _cam_forward(x, gamma_c, _as3(feats[:, Cn:]))
+        ctx.save_for_backward(x, wq, wk, wv, gamma_p, gamma_c, att, *saved)
+        ctx.cfg = (prec, fused, (bq is not None, bk is not None, bv is not None))
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        x, wq, wk, wv, gamma_p, gamma_c, att, *saved = ctx.saved_tensors
+        prec, fused, has_bias = ctx.cfg
+        B, Cn, H, W = x.shape
+        dfeat = _c(dfeat)
+        d_pam, d_cam = _as3(dfeat[:, :Cn]), _as3(dfeat[:, Cn:])
+        dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
+        K.copy_slab(d_pam, dx)                     # residual path of PAM
+        K.copy_slab(d_cam, dx, accumulate=True)    # residual path of CAM
+        dgc = _cam_backward(att, x, gamma_c, d_cam, dx)
+        dwq, dbq, dwk, dbk, dwv, dbv, dgp = _pam_backward(fused, saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has_bias)
+        return dx.view(B, Cn, H, W), dwq, dbq, dwk, dbk, dwv, dbv, dgp, dgc
+
+
+def _as3(t: torch.Tensor) -> torch.Tensor:
+    """(B, C, H, W) view (possibly a channel slice) -> (B, C, H*W) view with the same batch stride"""
+    B, Cn, H, W = t.shape
+    return t.as_strided((B, Cn, H * W), (t.stride(0), H * W, 1), t.storage_offset())
+
+
+def _axpy_dev3(src: torch.Tensor, s: torch.Tensor, dst3: torch.Tensor) -> None:
+    """dst3 (strided per image) += s * src (dense), image by image stride aware"""
+    B = src.shape[0]
+    if dst3.is_contiguous():
+        K.scale_dev(src, s, out=dst3, accumulate=True)
+        return
+    for b in range(B):
+        K.scale_dev(src[b], s, out=dst3[b], accumulate=True)
+
+
+def _compact(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """(B, Rp, Np) padded plane -> dense (B, rows, cols)"""
+    B, Rp, Np = t.shape
+    if Rp == rows and Np == cols:
+        return t
+    if Np == cols:
+        return t[:, :rows]          # per-image dense channel slice: kernels take the batch stride
+    out = torch.empty(B, rows, cols, device=t.device, dtype=torch.float32)
+    K.copy_rows(t, Rp * Np, Np, out, rows * cols, cols, B, rows, cols)
+    return out
+
+
+# =====================================================================================================
+# resampling
+# =====================================================================================================
+class BicubicFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho: int, Wo: int, rsh: float, rsw: float):
+        x = _c(x)
+        ctx.cfg = (x.shape[2], x.shape[3], rsh, rsw)
+        return K.bicubic_fwd(x, Ho, Wo, rsh, rsw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Hi, Wi, rsh, rsw = ctx.cfg
+        return K.bicubic_bwd(_c(dy), Hi, Wi, rsh, rsw), None, None, None, None
+
+
+def bicubic_up2(x):
+    return BicubicFn.apply(x, 2 * x.shape[2], 2 * x.shape[3], 0.5, 0.5)
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho: int, Wo: int):
+        x = _c(x)
+        ctx.cfg = (x.shape[2], x.shape[3])
+        return K.bilinear_fwd(x, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Hi, Wi = ctx.cfg
+        return K.bilinear_bwd(_c(dy), Hi, Wi), None, None
+
+
+class SkipFuseFn(Function):
+    """x + sum_k adjust_k(bilinear_up(f_k))  ==  x + bilinear_up(sum_k adjust_k(f_k))   (generator.py:243-245)
+    The 1x1 ``channel_adjust`` convs (no bias) commute with the bilinear resize (both linear), so they run at
+    the LOW resolution (16x fewer pixels) and all skips share one upsample-add.
+    args: x, then n weights, then n features."""
+
+    @staticmethod
+    def forward(ctx, x, *wf):
+        prec = _prec()
+        n = len(wf) // 2
+        ws, fs = wf[:n], [_c(f) for f in wf[n:]]
+        x = _c(x)
+        B, Co, Ho, Wo = x.shape
+        s = K.conv2d_fwd(fs[0], ws[0], None, 1, 0, prec)
+        for w, f in zip(ws[1:], fs[1:]):
+            if f.shape[2:] != fs[0].shape[2:]:
+                raise L.GandanetError("SkipFuseFn: all skip features must share one resolution")
+            K.conv2d_fwd(f, w, None, 1, 0, prec, out=s, accumulate=True)
+        out = torch.empty_like(x)
+        K.copy_slab(x, out)
+        K.bilinear_fwd(s, Ho, Wo, out=out, accumulate=True)
+        ctx.save_for_backward(*ws, *fs)
+        ctx.cfg = (prec, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        prec, n = ctx.cfg
+        saved = ctx.saved_tensors
+        ws, fs = saved[:n], saved[n:]
+        dout = _c(dout)
+        Hi, Wi = fs[0].shape[2], fs[0].shape[3]
+        ds = K.bilinear_bwd(dout, Hi, Wi)
+        gw = [K.conv2d_wgrad(ds, f, 1, 1, 0, prec) for f in fs]
+        gf = [K.conv2d_dgrad(ds, w, (Hi, Wi), 1, 0, prec) for w in ws]
+        return (dout, *gw, *gf)
+
+
+class MaxPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return K.maxpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.maxpool2_bwd(x, _c(dy))
+
+
+# =====================================================================================================
+# linear (+ activation)                    nn.Linear / nn.LazyLinear (discriminator.py:66-67,76-77)
+# =====================================================================================================
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, act: int):
+        prec = _prec()
+        x = _c(x)
+        Bn, Kin = x.shape
+        Nout = w.shape[0]
+        y = torch.empty(Bn, Nout, device=x.device, dtype=torch.float32)
+        K.gemm_nt(B=1, M=Bn, N=Nout, kseg=1, klen=Kin, a=x, a_bs=0, a_ss=0, lda=Kin, bm=w, b_bs=0, b_ss=0, ldb=Kin,
+                  c=y, c_bs=0, ldc=Nout, precision=prec, bias=bias)
+        if act != ACT_NONE:
+            K.act_fwd(y, act, out=y)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (act, prec, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, prec, has_bias = ctx.cfg
+        dy = _c(dy)
+        if act != ACT_NONE:
+            dy = K.act_bwd(y, dy, act)
+        Bn, Kin = x.shape
+        Nout = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:   # dX[b][k] = sum_o dY[b][o] W[o][k]  (1x1 "conv" over the k axis)
+            dx = torch.empty(Bn, Kin, device=x.device, dtype=torch.float32)
+            K.conv_nn(B=1, M=Bn, Ck=Nout, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=Kin, Ho=1, Wo=Kin, a=dy,
+                      a_bs=0, a_sm=Nout, a_sc=1, a_st=0, x=w, x_bs=0, y=dx, y_bs=0, precision=prec)
+        if ctx.needs_input_grad[1]:   # dW[o][k] = sum_b dY[b][o] X[b][k]
+            dw = torch.empty(Nout, Kin, device=x.device, dtype=torch.float32)
+            K.conv_nn(B=1, M=Nout, Ck=Bn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=Kin, Ho=1, Wo=Kin, a=dy,
+                      a_bs=0, a_sm=1, a_sc=Nout, a_st=0, x=x, x_bs=0, y=dw, y_bs=0, precision=prec)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = K.channel_sum(dy.view(Bn, Nout, 1))
+        return dx, dw, db, None
+
+
+def linear(x, w, bias=None, act=ACT_NONE):
+    return LinearFn.apply(x, w, bias, act)
+
+
+# =====================================================================================================
+# losses
+# =====================================================================================================
+class _ScalarLoss(Function):
+    """common backward: upstream is a 0-dim device tensor; the stored gradient is scaled by it on device"""
+
+    @staticmethod
+    def _finish(ctx, out, grad):
+        ctx.save_for_backward(grad)
+        return out.view(())
+
+    @staticmethod
+    def _bwd(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return K.scale_dev(grad, _c(gout).view(1))
+
+
+class BceLogitsFn(Function):
+    @staticmethod
+    def forward(ctx, z, label: float):
+        out, dz = K.bce_logits(_c(z), label, True)
+        return _ScalarLoss._finish(ctx, out, dz)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScalarLoss._bwd(ctx, g), None
+
+
+class MseFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out, da = K.diff_loss("mse", _c(a), _c(b), True)
+        return _ScalarLoss._finish(ctx, out, da)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScalarLoss._bwd(ctx, g), None
+
+
+class L1Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out, da = K.diff_loss("l1", _c(a), _c(b), True)
+        ctx.b_needs = b.requires_grad
+        return _ScalarLoss._finish(ctx, out, da)
+
+    @staticmethod
+    def backward(ctx, g):
+        da = _ScalarLoss._bwd(ctx, g)
+        db = None
+        if ctx.needs_input_grad[1]:
+            db = K.axpby(da, -1.0, torch.empty_like(da), 0.0)
+        return da, db
+
+
+class TvFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight: float):
+        out, dx = K.tv(_c(x), weight, True)
+        return _ScalarLoss._finish(ctx, out, dx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScalarLoss._bwd(ctx, g), None
+
+
+def bce_with_logits(z, label: float):
+    return BceLogitsFn.apply(z, float(label))
+
+
+def mse_loss(a, b):
+    return MseFn.apply(a, b)
+
+
+def l1_loss(a, b):
+    return L1Fn.apply(a, b)
+
+
+def tv_loss(x, weight: float):
+    return TvFn.apply(x, float(weight))
+
+
+def ssim_value(a, b, window: int = 11):
+    """forward-only SSIM mean (the train loop evaluates it but never differentiates it)"""
+    with torch.no_grad():
+        return K.ssim(_c(a), _c(b), window).view(())
+
+
+class AddScalarsFn(Function):
+    """sum_k coef_k * t_k of 0-dim device tensors without a host sync (loss_G composition, L267)."""
+
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        ctx.coefs = coefs
+        out = torch.zeros(1, device=terms[0].device, dtype=torch.float32)
+        for c, t in zip(coefs, terms):
+            K.axpby(t.reshape(1), float(c), out, 1.0)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g1 = _c(g).view(1)
+        outs = []
+        for c in ctx.coefs:
+            outs.append(K.axpby(g1, float(c), torch.empty_like(g1), 0.0).view(()))
+        return (None, *outs)
+
+
+def weighted_sum(coefs, terms):
+    return AddScalarsFn.apply(tuple(coefs), *terms)
+
+
+# =====================================================================================================
+# small glue ops
+# =====================================================================================================
+class RepeatChannelsFn(Function):
+    """x.repeat(1, n, 1, 1) for a 1-channel image (losses.py:64-65)"""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        x = _c(x)
+        B, one, H, W = x.shape
+        if one != 1:
+            raise L.GandanetError("repeat_channels expects a 1-channel tensor")
+        out = torch.empty(B, n, H, W, device=x.device, dtype=torch.float32)
+        for i in range(n):
+            K.copy_slab(x, out[:, i:i + 1])
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        B, n, H, W = dy.shape
+        dx = torch.empty(B, 1, H, W, device=dy.device, dtype=torch.float32)
+        K.copy_slab(dy[:, 0:1], dx)
+        for i in range(1, n):
+            K.copy_slab(dy[:, i:i + 1], dx, accumulate=True)
+        return dx, None
+
+
+def repeat_channels(x, n: int):
+    return RepeatChannelsFn.apply(x, n)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        K.copy_slab(a.view(1, -1, 1), out.view(1, -1, 1))
+        K.axpby(b, 1.0, out, 1.0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class GlobalAvgPoolFn(Function):
+    """AdaptiveAvgPool2d(1) + flatten: (B, C, H, W) -> (B, C)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, Cn, H, W = x.shape
+        s = K.channel_sum(x.view(1, B * Cn, H * W))
+        K.axpby(s, 1.0 / (H * W), s, 0.0)
+        ctx.shape = (B, Cn, H, W)
+        return s.view(B, Cn)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cn, H, W = ctx.shape
+        shift = K.axpby(_c(dy).view(-1), 1.0 / (H * W), torch.empty(B * Cn, device=dy.device), 0.0)
+        zero = torch.zeros(B * Cn, device=dy.device, dtype=torch.float32)
+        dx = torch.zeros(1, B * Cn, H * W, device=dy.device, dtype=torch.float32)
+        K.affine_act(dx, zero, shift, ACT_NONE, out=dx)   # broadcast shift over the plane
+        return dx.view(B, Cn, H, W)
+
+
+def global_avg_pool(x):
+    return GlobalAvgPoolFn.apply(x)

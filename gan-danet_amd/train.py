@@ -1,0 +1,94 @@
+"""The G+D update of ``ModelTrainer.train`` (GAN_DANet_train.ipynb:L225-272) driven through the HIP-backed
+modules, sharded over GPUs with ``parallel.GradReducer``.
+
+Order kept from the reference: ONE generator forward per step, reused by both updates; D is updated BEFORE
+the generator loss is evaluated; ``loss_G = (1-w) MSE + w BCE(D(hr), 1) + TV + Perceptual`` with
+``w = epoch/epochs``; SSIM is evaluated and not used.  Deliberate, observable-state-preserving differences:
+
+* during the G step D's parameters do not require grad, so its weight gradients (which the reference computes
+  and then discards at the next ``optimizer_D.zero_grad()``, L246) are never formed -- for Discriminator1.fc1
+  that is 2.1e9 elements per step at 256x256 tiles;
+* loss scalars stay on the device; ``.item()`` (the reference's two host syncs per step, L271-272) is left to
+  the caller.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .optim import AdamW
+from .parallel import GradReducer, world_size
+
+
+@dataclass
+class StepOutput:
+    loss_d: torch.Tensor
+    loss_g: torch.Tensor
+    parts: Dict[str, torch.Tensor]
+    hr: torch.Tensor
+
+
+class GanTrainer:
+    def __init__(self, G: nn.Module, D: nn.Module, perceptual: Optional[nn.Module] = None, lr_g: float = 2e-4,
+                 lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
+                 compute_ssim: bool = True, tv_global_batch_semantics: bool = False) -> None:
+        self.G, self.D, self.perceptual = G, D, perceptual
+        ws = world_size()
+        self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
+        self.opt_g = AdamW(G.parameters(), lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
+        self.red_d = GradReducer(D.parameters())
+        self.red_g = GradReducer(G.parameters())
+        # TVLoss divides by the batch size twice (losses.py:82-87): per-shard TV averaged over ranks is `world`
+        # times the single-device global-batch value.  Default = plain DDP semantics (per-shard loss, as the
+        # per-shard oracle computes it); set tv_global_batch_semantics to scale it back by 1/world.
+        self.tv_weight = tv_weight / ws if tv_global_batch_semantics else tv_weight
+        self.compute_ssim = compute_ssim
+
+    def step(self, x: torch.Tensor, target: torch.Tensor, loss_weight: float) -> StepOutput:
+        G, D = self.G, self.D
+        hr = G(x)
+
+        # ---- discriminator update (L246-256) ----
+        self.opt_d.zero_grad(set_to_none=True)
+        real = D(target)
+        fake = D(hr.detach())
+        loss_d = ops.weighted_sum([0.5, 0.5], [ops.bce_with_logits(real, 1.0), ops.bce_with_logits(fake, 0.0)])
+        loss_d.backward()
+        self.red_d.reduce()
+        self.opt_d.step()
+
+        # ---- generator update (L259-269) ----
+        self.opt_g.zero_grad(set_to_none=True)
+        d_flags = [p.requires_grad for p in D.parameters()]
+        for p in D.parameters():
+            p.requires_grad_(False)
+        try:
+            fake = D(hr)
+            adv = ops.bce_with_logits(fake, 1.0)
+            pix = ops.mse_loss(hr, target)
+            ssim_term = ops.ssim_value(hr.detach(), target) if self.compute_ssim else None
+            tv = ops.tv_loss(hr, self.tv_weight)
+            terms, coefs = [pix, adv, tv], [1.0 - loss_weight, loss_weight, 1.0]
+            perc = None
+            if self.perceptual is not None:
+                perc = self.perceptual(hr, target)
+                terms.append(perc)
+                coefs.append(1.0)
+            loss_g = ops.weighted_sum(coefs, terms)
+            loss_g.backward()
+        finally:
+            for p, f in zip(D.parameters(), d_flags):
+                p.requires_grad_(f)
+        self.red_g.reduce()
+        self.opt_g.step()
+
+        parts = {"adv": adv.detach(), "pix": pix.detach(), "tv": tv.detach()}
+        if perc is not None:
+            parts["perc"] = perc.detach()
+        if ssim_term is not None:
+            parts["ssim"] = ssim_term   # SSIM value; the reference logs 1 - SSIM and never uses it
+        return StepOutput(loss_d.detach(), loss_g.detach(), parts, hr.detach())

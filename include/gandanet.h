@@ -1,0 +1,221 @@
+/* gandanet.h -- C ABI of libgandanet_hip.so: the MI355X (gfx950) kernels behind the
+ * GAN-DANet G+D training hot path.
+ *
+ * The reference (Aster32/GAN-DANet) has no native code and no FFI: its boundary for this
+ * path is the Python nn.Module surface (models/__init__.py:12-23), and the arithmetic is
+ * whatever ATen kernel each nn.* / F.* line dispatches to.  Each entry point below replaces
+ * one such ATen call site; the reference line(s) it stands in for are cited per function.
+ * INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (outputs and
+ *     workspaces included); the library allocates nothing and keeps no pointer after return;
+ *   - tensors are dense row-major fp32 NCHW unless a parameter says otherwise; "bs" = batch
+ *     stride in ELEMENTS (lets a call address a channel slice of a wider slab);
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (no host sync);
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure); the message is
+ *     retrievable with gd_last_error(); nothing throws across the boundary;
+ *   - re-entrant; no global state except the last-error string (thread-local).
+ */
+#ifndef GANDANET_H
+#define GANDANET_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_VERSION 100 /* 0.1.0 */
+int gd_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int gd_last_error(char* buf, int n);
+/* sizeof() of the two descriptor structs below, so a foreign binding can verify its mirror */
+int gd_sizeof_conv_desc(void);
+int gd_sizeof_gemm_nt_desc(void);
+
+enum { GD_PREC_FP32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32) */
+       GD_PREC_BF16 = 1  /* bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16) */ };
+enum { GD_ACT_NONE = 0, GD_ACT_RELU = 1, GD_ACT_LEAKY02 = 2 };
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, "NN" form:   out[b][m][p] = sum_{tap,c} A[b][m][c][tap] * X~[b][c][p (+) tap]
+ * One kernel serves nn.Conv2d forward (generator.py:20,34,63,108-110,148,188,214,218,222,228;
+ * discriminator.py:62-65; VGG convs losses.py:41), its data gradient (transposed gather),
+ * CAM's attention*X product with per-batch "weights" (generator.py:137), and the
+ * data/weight gradients of nn.Linear (discriminator.py:66-67) viewed as 1x1 convolutions.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gd_conv_desc {
+    int B;          /* batch count (grid z) */
+    int M;          /* rows of A that exist (Cout forward, Cin for the data gradient) */
+    int Mstore;     /* rows written (>= M; rows in [M, Mstore) are written as zeros + epilogue) */
+    int Ck;         /* reduction channels (Cin forward, Cout for the data gradient) */
+    int ks;         /* square kernel size (1, 3, ...) */
+    int stride, pad;
+    int transposed; /* 0: iy = oy*stride - pad + kh;  1: iy = (oy + pad - kh)/stride where divisible */
+    int Hi, Wi;     /* spatial size of the tensor X being gathered */
+    int Ho, Wo;     /* spatial size of the output */
+    /* A element (b, m, c, tap) at a[b*a_bs + m*a_sm + c*a_sc + tap*a_st] */
+    const float* a; long a_bs, a_sm, a_sc, a_st;
+    /* X element (b, c, y, x) at x[b*x_bs + c*Hi*Wi + y*Wi + x] */
+    const float* x; long x_bs;
+    /* optional fused input transform X~ = relu?(X*in_scale[c] + in_shift[c]) (BatchNorm+ReLU of
+       generator.py:36 folded into the consumer); padding stays zero.  NULL = identity */
+    const float* in_scale; const float* in_shift; int in_relu;
+    /* output */
+    void* y; long y_bs;
+    int out_layout;  /* 0: y[b*y_bs + m*Ho*Wo + p];  1: y[b*y_bs + p*ldo + m] (pixel-major) */
+    int out_bf16;    /* 0 fp32, 1 bf16 */
+    int ldo;
+    /* epilogue: v = acc * (alpha ? *alpha : 1) + bias[m] + res[b*res_bs + m*Ho*Wo + p]; act; y (+)= v */
+    const float* alpha; const float* bias; const float* res; long res_bs;
+    int act; int accumulate;
+    int precision;
+} gd_conv_desc;
+int gd_conv2d(const gd_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * "NT" GEMM with the long reduction split over workgroups:
+ *     C[b][m][n] (+)= alpha * sum_k A[b][m][k] * B~[b][n][k]        (k contiguous in both)
+ * k runs over `kseg` segments of `klen` elements (segment = one image of a batch).
+ * Serves the convolution weight gradient (B~ = im2col rows, k = output pixels), CAM's Gram
+ * matrix X X^T (generator.py:133), nn.Linear forward (discriminator.py:76-77) and the
+ * unfused fp32 PAM products (generator.py:117,120).
+ * Partial sums of different k-splits are combined with fp32 atomics.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gd_gemm_nt_desc {
+    int B, M, N;
+    int kseg; long klen;
+    /* A element (b, m, s, kk) at a[b*a_bs + s*a_ss + m*lda + kk] */
+    const float* a; long a_bs, a_ss, lda;
+    /* B plain (im2col == 0): element (b, n, s, kk) at bm[b*b_bs + s*b_ss + n*ldb + kk] */
+    const float* bm; long b_bs, b_ss, ldb;
+    /* B as im2col rows (im2col == 1): n = c*ks*ks + tap, kk = oy*Wo + ox of an Ho x Wo output;
+       element = X~[s][c][oy*stride - pad + kh][ox*stride - pad + kw], X at bm[s*b_ss + c*Hi*Wi + ...] */
+    int im2col, ks, stride, pad, Hi, Wi, Ho, Wo;
+    const float* in_scale; const float* in_shift; int in_relu;
+    /* C element (b, m, n) at c[b*c_bs + m*ldc + n]; fp32 */
+    float* c; long c_bs, ldc;
+    const float* alpha;  /* device scalar or NULL */
+    const float* bias;   /* per-n bias (added once) or NULL */
+    int accumulate;      /* 0: C is overwritten (zeroed first when splits > 1);  1: C += */
+    int splits;          /* k-splits (>=1); 0 = library picks */
+    int precision;
+} gd_gemm_nt_desc;
+int gd_gemm_nt(const gd_gemm_nt_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d (generator.py:32,61,149,189,219,223).  x is (B, C, H, W) with batch stride x_bs.
+ * ---------------------------------------------------------------------------------------- */
+/* per-channel batch statistics -> mean[C], invstd[C]; if running_* != NULL they are blended
+ * (momentum, unbiased variance) exactly like nn.BatchNorm2d in train mode.
+ * ws: workspace of gd_bn_stats_ws_floats(...) floats. */
+size_t gd_bn_stats_ws_floats(int B, int C, long HW);
+int gd_bn_stats(const float* x, long x_bs, int B, int C, long HW, float eps, float momentum,
+                float* mean, float* invstd, float* running_mean, float* running_var, float* ws, void* stream);
+/* scale[c] = gamma[c]*invstd[c], shift[c] = beta[c] - mean[c]*scale[c]  (the folded affine) */
+int gd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* invstd, int C,
+               float* scale, float* shift, void* stream);
+/* eval mode: invstd from running_var (also written to invstd_out when non-NULL) */
+int gd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    float eps, int C, float* scale, float* shift, float* invstd_out, void* stream);
+/* out[c] (+)= sum over (B, HW) of x[b][c][:]  (bias gradients); ws: gd_bn_stats_ws_floats(B, C, HW) floats */
+int gd_channel_sum(const float* x, long x_bs, int B, int C, long HW, float* out, int accumulate, float* ws,
+                   void* stream);
+/* y = act(x*scale[c] + shift[c]) */
+int gd_affine_act(const float* x, long x_bs, const float* scale, const float* shift, int B, int C, long HW,
+                  int act, float* y, long y_bs, void* stream);
+/* backward of y = act(bn(x)): given dy (grad of y), x, the folded scale/shift, mean, invstd, gamma:
+ * dgamma[C], dbeta[C] (overwritten) and dx (+)= ... ; ws as gd_bn_stats_ws_floats. */
+int gd_bn_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const float* scale, const float* shift,
+                  const float* mean, const float* invstd, const float* gamma, int B, int C, long HW, int act,
+                  int train, float* dgamma, float* dbeta, float* dx, long dx_bs, int accumulate_dx, float* ws,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling (nn.Upsample bicubic generator.py:221,225; F.interpolate bilinear generator.py:244;
+ * bicubic down-sampling GAN_DANet_train.ipynb:L226,L231; VGG max-pool).
+ * rscale_* = the coordinate scale ATen uses (1/scale_factor, or in/out when a size was given).
+ * ---------------------------------------------------------------------------------------- */
+int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, float rscale_h,
+                   float rscale_w, void* stream);
+int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, float rscale_h,
+                   float rscale_w, void* stream); /* dx (BC,Hi,Wi) overwritten */
+/* y (+)= bilinear(x): accumulate=1 fuses the skip addition of generator.py:245 */
+int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate, void* stream);
+int gd_bilinear_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, void* stream);
+int gd_maxpool2_fwd(const float* x, int BC, int Hi, int Wi, float* y, void* stream);
+int gd_maxpool2_bwd(const float* x, const float* dy, int BC, int Hi, int Wi, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pointwise / small reductions
+ * ---------------------------------------------------------------------------------------- */
+/* y = act(x) ; dx = dy * act'(y) computed from the OUTPUT y (valid for relu / leaky) */
+int gd_act_fwd(const float* x, float* y, long n, int act, void* stream);
+int gd_act_bwd(const float* y, const float* dy, float* dx, long n, int act, void* stream);
+/* y = a*x + b*y  (a, b host scalars) */
+int gd_axpby(const float* x, float a, float* y, float b, long n, void* stream);
+/* y = (*s_dev) * x  (scale by a device scalar: loss weights / upstream scalar gradients, no host sync) */
+int gd_scale_dev(const float* x, const float* s_dev, float* y, long n, int accumulate, void* stream);
+/* dst[b][r][c] = src[b][r][c], r < R, c < Cc, independent batch strides and leading dimensions */
+int gd_copy_rows(const float* src, long s_bs, long s_ld, float* dst, long d_bs, long d_ld, int B, int R, int Cc,
+                 void* stream);
+/* strided copy of a (B, C, HW) block: dst[b*d_bs + i] (+)= src[b*s_bs + i], i < C*HW */
+int gd_copy_slab(const float* src, long s_bs, float* dst, long d_bs, int B, long chw, int accumulate, void* stream);
+/* row softmax, in place capable: y[r][:] = softmax(sign * x[r][:]) over `cols` (CAM uses sign=-1:
+ * softmax(max - E) == softmax(-E), generator.py:134-135) */
+int gd_softmax_rows(const float* x, float* y, long rows, int cols, float sign, void* stream);
+/* dx[r][:] = sign * p .* (dp - sum(dp .* p)) */
+int gd_softmax_rows_bwd(const float* p, const float* dp, float* dx, long rows, int cols, float sign, void* stream);
+/* out[0] (+)= sum_i a[i]*b[i]  (b == NULL: sum_i a[i]) -- gamma gradients ; ws >= 1024 floats */
+int gd_dot(const float* a, const float* b, long n, float* out, int accumulate, float* ws, void* stream);
+/* t[b][j][i] = s[b][i][j] : (B, R, Cc) -> (B, Cc, R) */
+int gd_transpose(const float* s, float* t, int B, int R, int Cc, void* stream);
+/* out = a + a^T for (B, n, n) */
+int gd_add_transpose(const float* a, float* out, int B, int n, void* stream);
+
+/* losses: value -> out[0] (fp32), gradient written when the pointer is non-NULL.  ws >= 2048 floats.
+ * BCEWithLogits mean vs a constant label (GAN_DANet_train.ipynb:L190,L252-253,L261) */
+int gd_bce_logits(const float* z, long n, float label, float* out, float* dz, float* ws, void* stream);
+/* MSELoss / L1 mean (L191,L262; losses.py:72) */
+int gd_mse(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream);
+int gd_l1(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream);
+/* TVLoss.forward (losses.py:81-87) */
+int gd_tv(const float* x, int B, int C, int H, int W, float weight, float* out, float* dx, float* ws, void* stream);
+/* SSIM mean (losses.py:109-136), forward only (the train loop never differentiates it) */
+int gd_ssim(const float* a, const float* b, int BC, int H, int W, int window, float* out, float* ws, void* stream);
+
+/* AdamW step over one tensor (torch.optim.AdamW, GAN_DANet_train.ipynb:L182-183).
+ * `step` is 1-based.  The gradient is read once, multiplied by grad_scale (1/world for DP). */
+int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
+             float eps, float weight_decay, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PAM, fused (flash) form in bf16 with fp32 softmax statistics (generator.py:115-122).
+ *   qt, kt : (B, Npad, 32) bf16, d zero-padded to 32      (pixel-major)
+ *   v      : (B, Cp, Npad) bf16, Cp = C rounded up to 32   (channel-major)
+ *   x, out : (B, C, N) fp32 with batch strides; out = gamma * attn + x
+ *   o_attn : (B, C, N) fp32 un-scaled attention output (kept for backward), lse : (B, N) fp32
+ * ---------------------------------------------------------------------------------------- */
+int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
+                     const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn,
+                     float* lse, void* stream);
+/* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad); vt (B,Npad,Cp);
+ * dot (B,Npad,Cp) and don (B,Cp,Npad) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
+ * outputs fp32: dqt (B,Npad,32) pixel-major, MUST be zeroed by the caller (accumulated with atomics);
+ * dkn (B,32,Npad) and dv (B,Cp,Npad) channel-major, overwritten. */
+int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
+                     const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
+                     int Npad, int Cp, float* dqt, float* dkn, float* dv, void* stream);
+/* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
+int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
+                float* d_raw, float* delta, void* stream);
+/* fp32 (B, R, Cc) planes (batch stride s_bs), optionally times a device scalar -> bf16:
+ *   plain      (B, Rp_plain, ld_plain)  zero padded copy          (NULL to skip)
+ *   transposed (B, Ccp_t, ld_t)         zero padded transpose     (NULL to skip) */
+int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, void* plain, int Rp_plain,
+                 int ld_plain, void* transposed, int Ccp_t, int ld_t, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANDANET_H */

@@ -1,0 +1,279 @@
+"""GPU parity, op level: each HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+fp32 mode = exact f32 MFMA -> tight tolerances; bf16 mode = bf16 MFMA operands, fp32 accumulate ->
+tolerance ~ 2^-8 relative to the output scale (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, assert_close, bf16_round, rell2, relmax, seeded
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 2e-5
+BF16_TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def gd():
+    import gan_danet_amd as g
+    from gan_danet_amd import _lib
+    _lib.load()
+    return g
+
+
+def _ops():
+    from gan_danet_amd import kern, ops
+    return ops, kern
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, bias
+    (2, 8, 16, 16, 64, 3, 1, 1, False),     # stem
+    (2, 88, 8, 8, 24, 3, 1, 1, True),       # dense layer (Cin not a multiple of 32)
+    (1, 184, 16, 16, 23, 1, 1, 0, True),    # PAM query projection
+    (2, 64, 16, 16, 1, 3, 1, 1, True),      # final conv (Cout = 1)
+    (2, 1, 32, 32, 64, 3, 2, 1, True),      # D conv1 (Cin = 1, stride 2)
+    (2, 64, 16, 16, 128, 3, 2, 1, True),    # D conv2
+    (1, 3, 20, 12, 64, 3, 1, 1, True),      # VGG first conv, non-square image
+    (1, 40, 9, 7, 136, 3, 1, 1, False),     # ragged: odd sizes, M > 128
+    (1, 16, 13, 11, 32, 4, 2, 1, True),     # SRGAND-style 4x4 stride 2
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(gd, case, prec):
+    ops, _ = _ops()
+    B, Cin, H, W, Cout, k, s, p, bias = case
+    x = seeded((B, Cin, H, W), 1)
+    w = seeded((Cout, Cin, k, k), 2, 1.0 / math.sqrt(Cin * k * k))
+    b = seeded((Cout,), 3, 0.1) if bias else None
+    if prec == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, stride=s, padding=p), 0.2)
+    go = seeded(tuple(yr.shape), 4)
+    if prec == "bf16":
+        go = bf16_round(go)
+    yr.backward(go)
+
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    with gd.precision(prec):
+        y = ops.conv2d(xg, wg, bg, s, p, ops.ACT_LEAKY)
+        y.backward(go.to(DEV))
+    tol = FP32_TOL if prec == "fp32" else BF16_TOL
+    assert_close(y, yr, tol, "y")
+    # in bf16 mode dy*act' is re-rounded to bf16 inside the kernels: compare in L2
+    assert_close(xg.grad, xr.grad, tol, "dx", rell2 if prec == "bf16" else relmax)
+    assert_close(wg.grad, wr.grad, tol, "dw", rell2 if prec == "bf16" else relmax)
+    if bias:
+        assert_close(bg.grad, br.grad, 1e-4, "db")
+
+
+def test_conv2d_slab_views_and_prologue(gd):
+    """conv reading a channel slice of a slab with the fused BN-affine+ReLU prologue, writing another slice"""
+    ops, K = _ops()
+    from gan_danet_amd import _lib as L
+    B, Ctot, H, W = 2, 48, 8, 8
+    slab = seeded((B, Ctot, H, W), 5).to(DEV)
+    w = seeded((8, 24, 3, 3), 6, 0.1).to(DEV)
+    bias = seeded((8,), 7).to(DEV)
+    sc, sh = (seeded((24,), 8).abs() + 0.5).to(DEV), seeded((24,), 9, 0.3).to(DEV)
+    ref_in = F.relu(slab[:, :24].cpu() * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+    ref = F.conv2d(ref_in, w.cpu(), bias.cpu(), padding=1)
+    before = slab.clone()
+    K.conv2d_fwd(slab[:, :24], w, bias, 1, 1, L.PREC_FP32, in_scale=sc, in_shift=sh, in_relu=True, out=slab[:, 40:48])
+    assert_close(slab[:, 40:48], ref, FP32_TOL, "slab conv")
+    assert torch.equal(slab[:, :40], before[:, :40]), "conv wrote outside its slice"
+    # weight gradient through the same prologue
+    dy = seeded((B, 8, H, W), 10).to(DEV)
+    dw = K.conv2d_wgrad(dy, slab[:, :24], 3, 1, 1, L.PREC_FP32, in_scale=sc, in_shift=sh, in_relu=True)
+    xin = ref_in.clone()
+    wr = w.cpu().clone().requires_grad_(True)
+    F.conv2d(xin, wr, None, padding=1).backward(dy.cpu())
+    assert_close(dw, wr.grad, FP32_TOL, "dw prologue")
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 8, 8), (3, 64, 33, 17), (2, 5, 150, 130)])
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm_act(gd, shape, train):
+    ops, _ = _ops()
+    B, Cn, H, W = shape
+    x = seeded(shape, 11) * 2 + 3.0     # offset mean: exercises the cancellation-safe statistics
+    gmm, bta = 1 + 0.1 * seeded((Cn,), 12), 0.1 * seeded((Cn,), 13)
+    rm, rv = 0.05 * seeded((Cn,), 14), 1 + 0.2 * seeded((Cn,), 15) ** 2
+    bn = torch.nn.BatchNorm2d(Cn)
+    with torch.no_grad():
+        bn.weight.copy_(gmm); bn.bias.copy_(bta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(train)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(bn(xr))
+    go = seeded(shape, 16)
+    yr.backward(go)
+
+    xg = x.to(DEV).requires_grad_(True)
+    g, b = gmm.to(DEV).requires_grad_(True), bta.to(DEV).requires_grad_(True)
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    y = ops.batch_norm_act(xg, g, b, rmg, rvg, train, 0.1, 1e-5, ops.ACT_RELU)
+    y.backward(go.to(DEV))
+    assert_close(y, yr, 2e-5, "y")
+    assert_close(xg.grad, xr.grad, 1e-4, "dx")
+    assert_close(g.grad, bn.weight.grad, 1e-4, "dgamma")
+    assert_close(b.grad, bn.bias.grad, 1e-4, "dbeta")
+    assert_close(rmg, bn.running_mean, 1e-5, "running_mean")
+    assert_close(rvg, bn.running_var, 1e-5, "running_var")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 2, 45, 22), (2, 4, 16, 32)])
+def test_bicubic_up2(gd, shape):
+    ops, _ = _ops()
+    x = seeded(shape, 21)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bicubic", align_corners=False)
+    go = seeded(tuple(yr.shape), 22)
+    yr.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.bicubic_up2(xg)
+    y.backward(go.to(DEV))
+    assert_close(y, yr, 1e-5, "y")
+    assert_close(xg.grad, xr.grad, 1e-5, "dx")
+
+
+def test_bicubic_downscale_forward(gd):
+    """the train-loop preamble F.interpolate(scale_factor=0.25 / 0.5, 'bicubic') (GAN_DANet_train.ipynb:L226,L231)"""
+    _, K = _ops()
+    x = seeded((2, 3, 32, 48), 23)
+    for sf in (0.5, 0.25):
+        yr = F.interpolate(x, scale_factor=sf, mode="bicubic", align_corners=False)
+        y = K.bicubic_fwd(x.to(DEV), yr.shape[2], yr.shape[3], 1 / sf, 1 / sf)
+        assert_close(y, yr, 1e-5, f"bicubic x{sf}")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 3, 8, 8), (32, 32)), ((1, 2, 45, 22), (180, 88)), ((1, 2, 7, 9), (14, 27))])
+def test_bilinear(gd, shape, out):
+    ops, _ = _ops()
+    x = seeded(shape, 24)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=out, mode="bilinear", align_corners=False)
+    go = seeded(tuple(yr.shape), 25)
+    yr.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.BilinearFn.apply(xg, out[0], out[1])
+    y.backward(go.to(DEV))
+    assert_close(y, yr, 1e-5, "y")
+    assert_close(xg.grad, xr.grad, 1e-5, "dx")
+
+
+def test_maxpool2(gd):
+    ops, _ = _ops()
+    x = seeded((2, 5, 12, 20), 26)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    go = seeded(tuple(yr.shape), 27)
+    yr.backward(go)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.MaxPool2Fn.apply(xg)
+    y.backward(go.to(DEV))
+    assert torch.equal(y.cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("dims", [(2, 8192, 1024), (3, 1024, 1), (5, 777, 130)])
+def test_linear(gd, dims, prec):
+    ops, _ = _ops()
+    Bn, Kin, Nout = dims
+    x, w, b = seeded((Bn, Kin), 31), seeded((Nout, Kin), 32, 1 / math.sqrt(Kin)), seeded((Nout,), 33, 0.1)
+    if prec == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.leaky_relu(F.linear(xr, wr, br), 0.2)
+    go = seeded((Bn, Nout), 34)
+    if prec == "bf16":
+        go = bf16_round(go)
+    yr.backward(go)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    with gd.precision(prec):
+        y = ops.linear(xg, wg, bg, ops.ACT_LEAKY)
+        y.backward(go.to(DEV))
+    tol = 5e-5 if prec == "fp32" else BF16_TOL
+    m = relmax if prec == "fp32" else rell2
+    assert_close(y, yr, tol, "y")
+    assert_close(xg.grad, xr.grad, tol, "dx", m)
+    assert_close(wg.grad, wr.grad, tol, "dw", m)
+    assert_close(bg.grad, br.grad, 1e-4, "db")
+
+
+def test_softmax_rows(gd):
+    _, K = _ops()
+    x = seeded((37, 184), 41, 5.0)
+    for sign in (1.0, -1.0):
+        p = K.softmax_rows(x.to(DEV), sign)
+        pr = torch.softmax(sign * x, -1)
+        assert_close(p, pr, 1e-5, "softmax")
+        dp = seeded((37, 184), 42)
+        xr = x.clone().requires_grad_(True)
+        torch.softmax(sign * xr, -1).backward(dp)
+        dx = K.softmax_rows_bwd(p, dp.to(DEV), sign)
+        assert_close(dx, xr.grad, 1e-4, "softmax bwd")
+
+
+def test_losses(gd, golden_dir):
+    from gpu_util import load_golden
+    ops, K = _ops()
+    fx = load_golden(golden_dir, "losses_32x32")
+    a = fx["a"].to(DEV).requires_grad_(True)
+    b = fx["b"].to(DEV)
+    tv = ops.tv_loss(a, 1e-5)
+    (g,) = torch.autograd.grad(tv, a)
+    assert_close(tv, fx["tv"], 1e-5, "tv")
+    assert_close(g, fx["gtv"], 1e-5, "dtv")
+    assert_close(ops.ssim_value(a, b, 11), fx["ssim"], 1e-4, "ssim")
+    z = fx["z"].to(DEV).requires_grad_(True)
+    l1 = ops.bce_with_logits(z, 1.0)
+    assert_close(l1, fx["bce1"], 1e-5, "bce1")
+    (gz,) = torch.autograd.grad(l1, z)
+    zr = fx["z"].clone().requires_grad_(True)
+    F.binary_cross_entropy_with_logits(zr, torch.ones_like(zr)).backward()
+    assert_close(gz, zr.grad, 1e-5, "dbce")
+    assert_close(ops.bce_with_logits(z, 0.0), fx["bce0"], 1e-5, "bce0")
+    ms = ops.mse_loss(a, b)
+    assert_close(ms, fx["mse"], 1e-5, "mse")
+    (gm,) = torch.autograd.grad(ms, a)
+    assert_close(gm, 2 * (fx["a"] - fx["b"]) / fx["a"].numel(), 1e-5, "dmse")
+    l1v = ops.l1_loss(a, b)
+    assert_close(l1v, (fx["a"] - fx["b"]).abs().mean(), 1e-5, "l1")
+    # weighted sum of scalars with a scalar upstream (the loss_G composition)
+    tot = ops.weighted_sum([0.5, 2.0], [ops.mse_loss(a, b), ops.tv_loss(a, 1e-5)])
+    (gt,) = torch.autograd.grad(tot, a)
+    assert_close(gt, 0.5 * gm.cpu() + 2.0 * fx["gtv"], 1e-5, "weighted sum grad")
+
+
+def test_adamw_matches_torch(gd):
+    from gan_danet_amd import AdamW
+    torch.manual_seed(0)
+    p0 = torch.randn(1000)
+    pr = torch.nn.Parameter(p0.clone())
+    pg = torch.nn.Parameter(p0.clone().to(DEV))
+    o_r = torch.optim.AdamW([pr], lr=4e-4, betas=(0.5, 0.999), weight_decay=1e-4)
+    o_g = AdamW([pg], lr=4e-4, betas=(0.5, 0.999), weight_decay=1e-4)
+    for t in range(5):
+        g = torch.randn(1000)
+        pr.grad, pg.grad = g.clone(), g.clone().to(DEV)
+        o_r.step(); o_g.step()
+    assert_close(pg, pr, 1e-6, "adamw params")
+
+
+def test_transpose_and_pack(gd):
+    _, K = _ops()
+    s = seeded((2, 23, 70), 51)
+    t = K.transpose(s.to(DEV))
+    assert torch.equal(t.cpu(), s.transpose(1, 2).contiguous())
+    plain, tr = K.pack_bf16(s.to(DEV), 23, 70, plain_shape=(32, 128), t_shape=(128, 32))
+    ref = torch.zeros(2, 32, 128); ref[:, :23, :70] = s
+    assert torch.equal(plain.float().cpu(), ref.to(torch.bfloat16).float())
+    assert torch.equal(tr.float().cpu(), ref.transpose(1, 2).to(torch.bfloat16).float())
