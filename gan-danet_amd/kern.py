@@ -65,6 +65,44 @@ def lib():
     return L.load()
 
 
+# ---- optional HIP-event brackets around the hot kernels (bench.py's live roofline measurement) -------------
+PROFILE_ON = False
+PROFILE: list = []   # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
+
+
+class _Bracket:
+    """records a start/end event pair on the stream the kernel is enqueued on (torch's current stream)"""
+
+    def __init__(self, name: str, flops: float, nbytes: float = 0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILE_ON:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_ON:
+            self.e1.record()
+            PROFILE.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+        return False
+
+
+def profile_summary():
+    """name -> (launches, avg ms, algorithmic flop per launch, algorithmic bytes per launch)"""
+    torch.cuda.synchronize()
+    agg = {}
+    for name, e0, e1, fl, nb in PROFILE:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += fl
+        a[3] += nb
+    return {k: (v[0], v[1] / v[0], v[2] / v[0], v[3] / v[0]) for k, v in agg.items()}
+
+
 # ------------------------------------------------------------------------------------------------
 # implicit-GEMM "NN" kernel
 # ------------------------------------------------------------------------------------------------
@@ -464,12 +502,18 @@ def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
     return d_raw, delta
 
 
-def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse):
-    L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, _ptr(gamma), _ptr(x), _bview(x),
-                                   _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()), "gd_pam_flash_fwd")
+def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32):
+    # algorithmic (unpadded) work: 2 N^2 (r + C) per image
+    with _Bracket("pam_flash_fwd", 2.0 * N * N * (r_alg + Cn) * B):
+        L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, _ptr(gamma), _ptr(x),
+                                       _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()),
+                "gd_pam_flash_fwd")
 
 
-def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqt, dkn, dv):
-    L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(qn), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(don), _ptr(lse),
-                                   _ptr(delta), B, N, Npad, Cp, _ptr(dqt), _ptr(dkn), _ptr(dv), _stream()),
-            "gd_pam_flash_bwd")
+def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqt, dkn, dv, r_alg: int = 32,
+                  c_alg: int = 0):
+    # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
+    with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
+        L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(qn), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(don),
+                                       _ptr(lse), _ptr(delta), B, N, Npad, Cp, _ptr(dqt), _ptr(dkn), _ptr(dv),
+                                       _stream()), "gd_pam_flash_bwd")

@@ -226,7 +226,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
         del q, k, v
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
-        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r)
         return True, (qt, kt, qn, kn, vt, o_attn, lse)
     qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)
     s = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
@@ -256,7 +256,7 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         dqt = torch.zeros(B, Np, 32, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
-        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqt, dkn, dvp)
+        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqt, dkn, dvp, r_alg=r, c_alg=Cn)
         dqn = K.transpose(dqt)                                   # (B, 32, Np)
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
