@@ -49,7 +49,11 @@ def cpu_baseline(nsteps: int):
     from oracle import modules as OM
     from oracle import step as OS
     torch.manual_seed(1234)
-    nthreads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))      # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(nthreads)
     G, D = OM.FlexibleUpsamplingModule(input_channels=8), OM.Discriminator1()
     x, tgt = torch.randn(1, 8, 64, 64), torch.randn(1, 1, 256, 256)
@@ -66,8 +70,13 @@ def cpu_baseline(nsteps: int):
     og, od = OS.AdamWState(lr=2e-4), OS.AdamWState(lr=4e-4)
     OS.train_step(G, D, og, od, x, tgt, 0.5, 1e-5, perc)   # warm-up
     t0 = time.perf_counter()
-    for _ in range(nsteps):
+    done = 0
+    for _ in range(nsteps):                                 # bounded: stop after ~25 s of CPU work
         OS.train_step(G, D, og, od, x, tgt, 0.5, 1e-5, perc)
+        done += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    nsteps = done
     dt = time.perf_counter() - t0
     return {"value": round(nsteps * 1 / dt, 4), "unit": "samples/s", "cores": nthreads, "kind": "port",
             "sample": f"{nsteps} G+D steps of BASELINE config 1 (B=1, 8ch 64x64 tile -> 256x256, fp32, "

@@ -24,6 +24,9 @@ namespace {
 using gd::acc_row;
 using gd::bf16x8_native_t;
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // staging registers: first-class vectors, never
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));   // demoted to scratch like arrays of uint4 structs
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -35,21 +38,18 @@ __device__ __forceinline__ f32x16_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c
 // registers 8s..8s+7 of a 32x32 accumulator -> the bf16 fragment of k-step s (k = accumulator ROW index,
 // element j of lane half h <-> row 16s + 8(j>>2) + 4h + (j&3))
 __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int s) {
-    union { bf16x8_t v; unsigned int u[4]; } f;
-    f.u[0] = gd_pack_bf2(a[8 * s + 0], a[8 * s + 1]);
-    f.u[1] = gd_pack_bf2(a[8 * s + 2], a[8 * s + 3]);
-    f.u[2] = gd_pack_bf2(a[8 * s + 4], a[8 * s + 5]);
-    f.u[3] = gd_pack_bf2(a[8 * s + 6], a[8 * s + 7]);
-    return f.v;
+    const u32x4_t w = {gd_pack_bf2(a[8 * s + 0], a[8 * s + 1]), gd_pack_bf2(a[8 * s + 2], a[8 * s + 3]),
+                       gd_pack_bf2(a[8 * s + 4], a[8 * s + 5]), gd_pack_bf2(a[8 * s + 6], a[8 * s + 7])};
+    return __builtin_bit_cast(bf16x8_t, w);
 }
 
 // A/B fragment whose k runs over an accumulator-row-ordered index stored contiguously in an LDS row:
 // elements [base + 4h .. +3] and [base + 8 + 4h .. +3]  (two 8-byte reads)
 __device__ __forceinline__ bf16x8_t read_perm_frag(const unsigned short* row, int base, int h) {
-    union { bf16x8_t v; uint2 u[2]; } f;
-    f.u[0] = *reinterpret_cast<const uint2*>(row + base + 4 * h);
-    f.u[1] = *reinterpret_cast<const uint2*>(row + base + 8 + 4 * h);
-    return f.v;
+    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(row + base + 4 * h);
+    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(row + base + 8 + 4 * h);
+    const u32x4_t w = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8_t, w);
 }
 
 // =====================================================================================================
@@ -94,28 +94,28 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
     const int nkt = (N + F_KT - 1) / F_KT;
 
     // staging registers: K tile = 256 x 16 B; V tile = CP*8 chunks of 16 B = CT per thread
-    uint4 kreg;
-    uint4 vreg[CT];
+    u32x4_t kreg;
+    u32x4_t vreg[CT];
     const int k_key = tid >> 2, k_chunk = tid & 3;
     auto load_tile = [&](int t) {
         const int k0 = t * F_KT;
-        kreg = *reinterpret_cast<const uint4*>(ktb + (long)(k0 + k_key) * 32 + k_chunk * 8);
+        kreg = *reinterpret_cast<const u32x4_t*>(ktb + (long)(k0 + k_key) * 32 + k_chunk * 8);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int idx = tid + i * 256;
             const int c = idx >> 3, qd = idx & 7;
-            vreg[i] = *reinterpret_cast<const uint4*>(vb + (long)c * Npad + k0 + qd * 8);
+            vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (long)c * Npad + k0 + qd * 8);
         }
     };
     auto store_tile = [&]() {
-        *reinterpret_cast<uint4*>(Ks + k_key * F_KLD + k_chunk * 8) = kreg;
+        *reinterpret_cast<u32x4_t*>(Ks + k_key * F_KLD + k_chunk * 8) = kreg;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int idx = tid + i * 256;
             const int c = idx >> 3, qd = idx & 7;
-            uint2* dst = reinterpret_cast<uint2*>(Vs + c * F_VLD + qd * 8);  // 136-B rows: 8-B aligned only
-            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
-            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+            u32x2_t* dst = reinterpret_cast<u32x2_t*>(Vs + c * F_VLD + qd * 8);  // 136-B rows: 8-B aligned only
+            dst[0] = u32x2_t{vreg[i].x, vreg[i].y};
+            dst[1] = u32x2_t{vreg[i].z, vreg[i].w};
         }
     };
 
@@ -219,48 +219,42 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
 }
 
 // =====================================================================================================
-// backward
+// backward, part 1: dK^T and dV^T  (key-parallel; a workgroup owns NW*32 keys and sweeps the queries)
 // =====================================================================================================
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
 constexpr int B_TLD = 36;   // transposed tiles rows [..][32 i] (72 B): 8-B reads, conflict free
-constexpr int B_SLD = 40;   // dS tile rows [i][32 j] (80 B)
 
-template <int CT>
-__global__ __launch_bounds__(256, 1) void pam_bwd_kernel(
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
-    const unsigned short* __restrict__ kn, const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_,
-    const unsigned short* __restrict__ don, const float* __restrict__ lse, const float* __restrict__ delta, int N,
-    int Npad, float* __restrict__ dqt, float* __restrict__ dkn, float* __restrict__ dv) {
+    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const unsigned short* __restrict__ don,
+    const float* __restrict__ lse, const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn,
+    float* __restrict__ dv) {
     constexpr int CP = CT * 32;
-    constexpr int DLD = CP + 8;  // dO tile rows [i][CP c] (+16 B): 16-B reads conflict free
+    constexpr int NT = NW * 64;
+    constexpr int DLD = CP + 8;                    // dO tile rows [i][CP c] (+16 B): 16-B reads conflict free
+    constexpr int NCHUNK = 256 + 256 * CT;         // 16-byte chunks staged per query tile
+    constexpr int NPRE = (NCHUNK + NT - 1) / NT;   // chunks per thread
     __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
     __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dSs[4 * 32 * B_SLD];
     __shared__ float Ls[32], Ds[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int j0 = blockIdx.x * 128 + wave * 32;  // this wave's 32 keys
+    const int j0 = blockIdx.x * (NW * 32) + wave * 32;  // this wave's 32 keys
     const long nb = (long)b * Npad;
 
-    // ---- persistent per-wave operands -------------------------------------------------------------------
-    // K as B operand of S = Q K^T (col j = r, k = d)
+    // ---- persistent per-wave operands: K (B operand of S = Q K^T), V (B operand of dP = dO V^T) ----
     bf16x8_t kfB[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
-    // V as B operand of dP = dO V^T (col j = r, k = c)
     bf16x8_t vfB[2 * CT];
 #pragma unroll
     for (int s = 0; s < 2 * CT; ++s)
         vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + s * 16 + 8 * h);
-    // K as B operand of dQ = dS K (col d = r, k = j in natural order): kn[d][j0 + 16s + 8h + jj]
-    bf16x8_t knB[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-        knB[s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + s * 16 + 8 * h);
 
     f32x16_t dvacc[CT], dkacc;
 #pragma unroll
@@ -271,55 +265,70 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(
         for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
 
     const bool key_ok = (j0 + r) < N;
-    unsigned short* dSw = dSs + wave * 32 * B_SLD;
-
     const int nqt = (N + 31) / 32;
+
+    // ---- staging: global -> registers (prefetch, issued before the MFMAs of the previous tile) -> LDS ----
+    u32x4_t pre[NPRE];
+    float pre_s = 0.f;
+    auto load_tile = [&](int qtile) {
+        const int i0 = qtile * 32;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int c = tid + k * NT;
+            if (c < 128) {                                   // Q rows [i][32 d]
+                pre[k] = *reinterpret_cast<const u32x4_t*>(qt + (nb + i0 + (c >> 2)) * 32 + (c & 3) * 8);
+            } else if (c < 256) {                            // Q^T rows [d][32 i]
+                const int c2 = c - 128;
+                pre[k] = *reinterpret_cast<const u32x4_t*>(qn + ((long)b * 32 + (c2 >> 2)) * Npad + i0 + (c2 & 3) * 8);
+            } else if (c < 256 + 128 * CT) {                 // dO rows [i][CP c]
+                const int c2 = c - 256;
+                const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
+                pre[k] = *reinterpret_cast<const u32x4_t*>(dot_ + (nb + i0 + i) * CP + ch * 8);
+            } else if (c < NCHUNK) {                         // dO^T rows [c][32 i]
+                const int c2 = c - 256 - 128 * CT;
+                pre[k] = *reinterpret_cast<const u32x4_t*>(don + ((long)b * CP + (c2 >> 2)) * Npad + i0 + (c2 & 3) * 8);
+            }
+        }
+        if (tid < 64) {
+            const int i = i0 + (tid & 31);
+            pre_s = i < N ? (tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int c = tid + k * NT;
+            if (c < 128) {
+                *reinterpret_cast<u32x4_t*>(Qs + (c >> 2) * B_QLD + (c & 3) * 8) = pre[k];
+            } else if (c < 256) {
+                const int c2 = c - 128;
+                u32x2_t* dst = reinterpret_cast<u32x2_t*>(QTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8);
+                dst[0] = u32x2_t{pre[k].x, pre[k].y};
+                dst[1] = u32x2_t{pre[k].z, pre[k].w};
+            } else if (c < 256 + 128 * CT) {
+                const int c2 = c - 256;
+                const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
+                *reinterpret_cast<u32x4_t*>(dOs + i * DLD + ch * 8) = pre[k];
+            } else if (c < NCHUNK) {
+                const int c2 = c - 256 - 128 * CT;
+                u32x2_t* dst = reinterpret_cast<u32x2_t*>(dOTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8);
+                dst[0] = u32x2_t{pre[k].x, pre[k].y};
+                dst[1] = u32x2_t{pre[k].z, pre[k].w};
+            }
+        }
+        if (tid < 32) Ls[tid] = pre_s;
+        else if (tid < 64) Ds[tid - 32] = pre_s;
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
     for (int qtile = 0; qtile < nqt; ++qtile) {
         const int i0 = qtile * 32;
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage the query tile: Q [i][d], Q^T [d][i], dO [i][c], dO^T [c][i], lse, delta --------------
-        if (tid < 128) {  // Q: 32 rows x 64 B = 128 chunks of 16 B
-            const int i = tid >> 2, ch = tid & 3;
-            *reinterpret_cast<uint4*>(Qs + i * B_QLD + ch * 8) =
-                *reinterpret_cast<const uint4*>(qt + (nb + i0 + i) * 32 + ch * 8);
-        } else {          // Q^T: 32 rows (d) x 64 B
-            const int t2 = tid - 128;
-            const int d = t2 >> 2, ch = t2 & 3;
-            const uint4 w = *reinterpret_cast<const uint4*>(qn + ((long)b * 32 + d) * Npad + i0 + ch * 8);
-            uint2* dst = reinterpret_cast<uint2*>(QTs + d * B_TLD + ch * 8);
-            dst[0] = make_uint2(w.x, w.y);
-            dst[1] = make_uint2(w.z, w.w);
-        }
-        // dO: 32 rows x CP*2 B = 32*CT*4 chunks
-#pragma unroll
-        for (int it = 0; it < (CT + 1) / 2; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < 32 * CT * 4) {
-                const int i = idx / (CT * 4), ch = idx - i * (CT * 4);
-                *reinterpret_cast<uint4*>(dOs + i * DLD + ch * 8) =
-                    *reinterpret_cast<const uint4*>(dot_ + (nb + i0 + i) * CP + ch * 8);
-            }
-        }
-        // dO^T: CP rows x 64 B = CP*4 chunks
-#pragma unroll
-        for (int it = 0; it < (CT + 1) / 2; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < CP * 4) {
-                const int c = idx >> 2, ch = idx & 3;
-                const uint4 w = *reinterpret_cast<const uint4*>(don + ((long)b * CP + c) * Npad + i0 + ch * 8);
-                uint2* dst = reinterpret_cast<uint2*>(dOTs + c * B_TLD + ch * 8);
-                dst[0] = make_uint2(w.x, w.y);
-                dst[1] = make_uint2(w.z, w.w);
-            }
-        }
-        if (tid < 32) {
-            const int i = i0 + tid;
-            Ls[tid] = i < N ? lse[(long)b * N + i] : 0.f;
-            Ds[tid] = i < N ? delta[(long)b * N + i] : 0.f;
-        }
-        __syncthreads();
+        if (qtile + 1 < nqt) load_tile(qtile + 1);
 
-        // ---- S' = Q K^T - lse  (rows i, lane j) ; P = exp(S') ---------------------------------------------
+        // ---- S' = Q K^T - lse (rows i, lane j) and dP - delta = dO V^T - delta -----------------------------
         f32x16_t sacc, dpacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -331,7 +340,6 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(
             const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
             sacc = mfma_bf16(qa, kfB[s], sacc);
         }
-        // ---- dP - delta = dO V^T - delta ----------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < 2 * CT; ++s) {
             const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
@@ -350,49 +358,143 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_kernel(
             pf[s] = pack_frag(sacc, s);
             dsf[s] = pack_frag(dpacc, s);
         }
-        // ---- dV^T[c][j] += dO^T[c][i] P[i][j] ------------------------------------------------------------
+        // ---- dV^T[c][j] += dO^T[c][i] P[i][j] ;  dK^T[d][j] += Q^T[d][i] dS[i][j] ---------------------------
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const unsigned short* row = dOTs + (ct * 32 + r) * B_TLD;
 #pragma unroll
             for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_perm_frag(row, s * 16, h), pf[s], dvacc[ct]);
         }
-        // ---- dK^T[d][j] += Q^T[d][i] dS[i][j] ------------------------------------------------------------
         {
             const unsigned short* row = QTs + r * B_TLD;
 #pragma unroll
             for (int s = 0; s < 2; ++s) dkacc = mfma_bf16(read_perm_frag(row, s * 16, h), dsf[s], dkacc);
         }
-        // ---- dQ[i][d] += dS[i][j] K[j][d] : dS through LDS (row i, k = j natural) -------------------------
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dSw[acc_row(e, h) * B_SLD + r] = gd_f2bf(dpacc[e]);
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private tile)
-        __builtin_amdgcn_wave_barrier();
-        f32x16_t dqacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dqacc[e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8_t dsa = *reinterpret_cast<const bf16x8_t*>(dSw + r * B_SLD + s * 16 + 8 * h);
-            dqacc = mfma_bf16(dsa, knB[s], dqacc);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = i0 + acc_row(e, h);
-            if (i < N) atomicAdd(dqt + (nb + i) * 32 + r, dqacc[e]);
+        __syncthreads();  // everyone is done reading this tile
+        if (qtile + 1 < nqt) {
+            store_tile();
+            __syncthreads();
         }
     }
 
     // ---- write dV^T (channel-major, coalesced along keys) and dK^T ----------------------------------------
     const int j = j0 + r;
-    if (j < Npad) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
+        for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+    for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+}
+
+// =====================================================================================================
+// backward, part 2: dQ^T  (query-parallel like the forward: a workgroup owns 128 queries and streams keys)
+//   S^T[j][i], dP^T[j][i] with the key on the accumulator rows and the query on the lane (lse/delta are lane
+//   constants), dS^T is the B operand of dQ^T[d][i] += K^T[d][j] dS^T[j][i]; dQ^T accumulates in registers --
+//   no atomics, deterministic, and it is stored channel-major (the layout the projection gradients read).
+// =====================================================================================================
+constexpr int Q_KT = 64;
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
+    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ lse,
+    const float* __restrict__ delta, int N, int Npad, float* __restrict__ dqn) {
+    constexpr int CP = CT * 32;
+    constexpr int VLD = CP + 8;   // V tile rows [key][CP c]: 16-B reads conflict free
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[Q_KT * F_KLD];    // K rows [key][32 d]
+    __shared__ __attribute__((aligned(16))) unsigned short KNs[32 * F_VLD];     // K^T rows [d][64 keys]
+    __shared__ __attribute__((aligned(16))) unsigned short VTs[Q_KT * VLD];     // V rows [key][CP c]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long nb = (long)b * Npad;
+    const int qi = q0 + r;
+
+    bf16x8_t qf[2], dof[2 * CT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + (nb + q0 + r) * 32 + s * 16 + 8 * h);
+#pragma unroll
+    for (int s = 0; s < 2 * CT; ++s)
+        dof[s] = *reinterpret_cast<const bf16x8_t*>(dot_ + (nb + q0 + r) * CP + s * 16 + 8 * h);
+    const float nlse = qi < N ? -lse[(long)b * N + qi] * LOG2E : 0.f;   // log2 domain
+    const float ndelta = qi < N ? -delta[(long)b * N + qi] : 0.f;
+
+    f32x16_t dq;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+
+    const int nkt = (N + Q_KT - 1) / Q_KT;
+    u32x4_t kreg, knreg, vreg[CT];
+    auto load_tile = [&](int t) {
+        const int k0 = t * Q_KT;
+        kreg = *reinterpret_cast<const u32x4_t*>(kt + (nb + k0 + (tid >> 2)) * 32 + (tid & 3) * 8);
+        knreg = *reinterpret_cast<const u32x4_t*>(kn + ((long)b * 32 + (tid >> 3)) * Npad + k0 + (tid & 7) * 8);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (4 * CT), ch = idx - row * (4 * CT);
+            vreg[i] = *reinterpret_cast<const u32x4_t*>(vt + (nb + k0 + row) * CP + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+        *reinterpret_cast<u32x4_t*>(Ks + (tid >> 2) * F_KLD + (tid & 3) * 8) = kreg;
+        u32x2_t* kd = reinterpret_cast<u32x2_t*>(KNs + (tid >> 3) * F_VLD + (tid & 7) * 8);
+        kd[0] = u32x2_t{knreg.x, knreg.y};
+        kd[1] = u32x2_t{knreg.z, knreg.w};
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (4 * CT), ch = idx - row * (4 * CT);
+            *reinterpret_cast<u32x4_t*>(VTs + row * VLD + ch * 8) = vreg[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < nkt; ++t) {
+        if (t + 1 < nkt) load_tile(t + 1);
+        const bool tail = (t + 1) * Q_KT > N;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16_t sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sacc[e] = 0.f;
+                dpacc[e] = ndelta;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
+                sacc = mfma_bf16(kf, qf[s], sacc);
+            }
+#pragma unroll
+            for (int s = 0; s < 2 * CT; ++s) {
+                const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(VTs + (sub * 32 + r) * VLD + s * 16 + 8 * h);
+                dpacc = mfma_bf16(va, dof[s], dpacc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = exp2f(fmaf(sacc[e], LOG2E, nlse));
+                if (tail && (t * Q_KT + sub * 32 + acc_row(e, h)) >= N) p = 0.f;
+                dpacc[e] = p * dpacc[e];  // dS^T
+            }
+            const unsigned short* krow = KNs + r * F_VLD;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                dq = mfma_bf16(read_perm_frag(krow, sub * 32 + s * 16, h), pack_frag(dpacc, s), dq);
+        }
+        __syncthreads();
+        if (t + 1 < nkt) {
+            store_tile();
+            __syncthreads();
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqn[((long)b * 32 + acc_row(e, h)) * Npad + qi] = dq[e];
 }
 
 }  // namespace
@@ -425,16 +527,28 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
 
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
                                 const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
-                                int Npad, int Cp, float* dqt, float* dkn, float* dv, void* stream) {
-    GD_CHECK_ARG(qt && kt && qn && kn && vt && dot_ && don && lse && delta && dqt && dkn && dv, "gd_pam_flash_bwd: null pointer");
-    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 128 >= N");
+                                int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream) {
+    GD_CHECK_ARG(qt && kt && qn && kn && vt && dot_ && don && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
-    dim3 grid(Npad / 128, B);
-    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+    hipStream_t s = (hipStream_t)stream;
+    // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
+    // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
+    if (Cp <= 160) {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0, s,
+                                                     (const unsigned short*)qt, (const unsigned short*)kt,
+                                                     (const unsigned short*)qn, (const unsigned short*)vt,
+                                                     (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
+                                                     N, Npad, dkn, dv));
+    } else {
+        hipLaunchKernelGGL((pam_bwd_dkv_kernel<6, 4>), dim3(Npad / 128, B), dim3(256), 0, s, (const unsigned short*)qt,
+                           (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
+                           (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);
+    }
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
                                                  (const unsigned short*)qt, (const unsigned short*)kt,
-                                                 (const unsigned short*)qn, (const unsigned short*)kn,
-                                                 (const unsigned short*)vt, (const unsigned short*)dot_,
-                                                 (const unsigned short*)don, lse, delta, N, Npad, dqt, dkn, dv));
+                                                 (const unsigned short*)kn, (const unsigned short*)vt,
+                                                 (const unsigned short*)dot_, lse, delta, N, Npad, dqn));
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -510,10 +510,10 @@ def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_a
                 "gd_pam_flash_fwd")
 
 
-def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqt, dkn, dv, r_alg: int = 32,
+def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32,
                   c_alg: int = 0):
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
         L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(qn), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(don),
-                                       _ptr(lse), _ptr(delta), B, N, Npad, Cp, _ptr(dqt), _ptr(dkn), _ptr(dv),
+                                       _ptr(lse), _ptr(delta), B, N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv),
                                        _stream()), "gd_pam_flash_bwd")

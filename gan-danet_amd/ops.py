@@ -201,7 +201,7 @@ class DenseBlockFn(Function):
 # dual attention: PAM || CAM into one 2C slab      generator.py:104-157
 # =====================================================================================================
 def _npad(n: int) -> int:
-    return (n + 127) // 128 * 128
+    return (n + 255) // 256 * 256
 
 
 def _cp(c: int) -> int:
@@ -253,11 +253,10 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
         dgamma_p = K.dot(d_raw, None)
         don, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, plain_shape=(Cp, Np), t_shape=(Np, Cp))
-        dqt = torch.zeros(B, Np, 32, device=x.device, dtype=torch.float32)
+        dqn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
-        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqt, dkn, dvp, r_alg=r, c_alg=Cn)
-        dqn = K.transpose(dqt)                                   # (B, 32, Np)
+        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn)
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
         qt_, kt_, v, p, o_attn = pam_saved

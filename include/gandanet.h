@@ -201,11 +201,11 @@ int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N
                      float* lse, void* stream);
 /* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad); vt (B,Npad,Cp);
  * dot (B,Npad,Cp) and don (B,Cp,Npad) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
- * outputs fp32: dqt (B,Npad,32) pixel-major, MUST be zeroed by the caller (accumulated with atomics);
- * dkn (B,32,Npad) and dv (B,Cp,Npad) channel-major, overwritten. */
+ * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad).  Two launches: a key-parallel
+ * kernel for dK/dV and a query-parallel kernel for dQ (no atomics: bitwise reproducible).  Npad % 256 == 0. */
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
                      const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
-                     int Npad, int Cp, float* dqt, float* dkn, float* dv, void* stream);
+                     int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream);
 /* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
 int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
                 float* d_raw, float* delta, void* stream);

@@ -38,7 +38,7 @@ def test_three_step_trajectory_fp32(golden_dir):
         # AdamW's first steps are sign-like (g/|g|): elements whose gradient is at round-off level move by
         # +-lr in either implementation, so outputs after 3 steps agree to ~5e-2, not to round-off
         assert_close(out.hr, fx["hr_last"], 1.5e-1, "hr after 3 steps", rell2)
-        assert_close(G.final.weight, fx["final_w"], 1e-4, "final.weight", rell2)
+        assert_close(G.final.weight, fx["final_w"], 5e-4, "final.weight", rell2)  # same sign-like-update effect
     # D weight grads are not formed in the G step, G's are
     assert all(p.grad is not None for p in G.parameters())
 
