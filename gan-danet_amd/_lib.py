@@ -56,6 +56,9 @@ SIGNATURES = {
     "gd_sizeof_gemm_nt_desc": (_i, []),
     "gd_conv2d": (_i, [C.POINTER(ConvDesc), _p]),
     "gd_gemm_nt": (_i, [C.POINTER(GemmNTDesc), _p]),
+    "gd_conv3x3_ws_bytes": (_sz, [_i, _i]),
+    "gd_conv3x3_eligible": (_i, [C.POINTER(ConvDesc)]),
+    "gd_conv3x3": (_i, [C.POINTER(ConvDesc), _p, _sz, _p]),
     "gd_bn_stats_ws_floats": (_sz, [_i, _i, _l]),
     "gd_bn_stats": (_i, [_p, _l, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
     "gd_bn_fold": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),

@@ -1,0 +1,227 @@
+// 3x3 / stride 1 / pad 1 convolution for gfx950 with an LDS-resident input patch ("halo tile").
+//
+// The generic implicit-GEMM kernel (gemm_conv.hip) re-gathers every input element once per tap: 9x the load,
+// convert and LDS-store work, which makes it VALU-bound.  Here a workgroup owns a TH x 32 pixel tile of one
+// image and BM output channels.  Per 32-channel chunk it stages the (TH+2) x 34 input patch ONCE
+// (fp32 -> optional BatchNorm affine + ReLU -> bf16, stored [pixel][channel]) and runs all nine taps from it:
+// the B fragment of tap (ky,kx) for output pixel (y,x) is simply the 16-byte read at patch row (y+ky, x+kx),
+// so every staged element feeds 9 MFMA k-steps.  Weights are pre-packed once per call into bf16
+// [m-tile][chunk][tap][BM][32] (taps flipped / channels swapped for the data gradient), so the A tiles are
+// plain 16-byte vector copies.  MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulate; each MFMA n-tile is one image
+// row segment of 32 pixels, so the epilogue stores 128-byte coalesced rows.
+#include "common.h"
+#include "tile_mma.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+using gd::acc_row;
+using gd::bf16x8_native_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 32;        // tile width in pixels (= MFMA N)
+constexpr int PW = TW + 2;    // patch width
+constexpr int CK = 32;        // channels per chunk
+constexpr int LD = CK + 8;    // LDS row: 32 channels + 8 pad (80 B): conflict-free 16-B fragment reads
+
+// ---- weight pre-pack: A[m][c][tap] (generic strides) -> bf16 wpack[mt][chunk][tap][BM][32] ----------------
+__global__ void pack_w_kernel(const float* __restrict__ a, long a_sm, long a_sc, long a_st, int M, int Ck, int flip,
+                              int BM, int nchunks, unsigned short* __restrict__ wp, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CK);
+        long t = i / CK;
+        const int mm = (int)(t % BM);
+        t /= BM;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int chunk = (int)(t % nchunks);
+        const int mt = (int)(t / nchunks);
+        const int m = mt * BM + mm, c = chunk * CK + cc;
+        float v = 0.f;
+        if (m < M && c < Ck) v = a[(long)m * a_sm + (long)c * a_sc + (long)(flip ? 8 - tap : tap) * a_st];
+        wp[i] = gd_f2bf(v);
+    }
+}
+
+template <int BM, int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc d, const unsigned short* __restrict__ wp,
+                                                             int tiles_x, int nchunks) {
+    constexpr int WAVES_M = 2, WAVES_N = 2;
+    constexpr int TM = BM / (32 * WAVES_M);       // 32-row m-tiles per wave
+    constexpr int TN = TH / WAVES_N;              // image rows (n-tiles) per wave
+    constexpr int PH = TH + 2;
+    constexpr int NPIX = PH * PW;
+    constexpr int WCHUNKS = 3 * BM * CK / 8;      // 16-byte vectors of one kernel row of weights
+    constexpr int WPT = WCHUNKS / 256;            // per thread
+    static_assert(WCHUNKS % 256 == 0, "weight stage must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) unsigned short patch[NPIX * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short wts[3 * BM * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int mt = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = d.Hi, W = d.Wi;
+    const long HW = (long)H * W;
+    const float* ximg = d.x + (long)b * d.x_bs;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const unsigned short* wbase = wp + (long)mt * nchunks * 9 * BM * CK;
+    u32x4_t wreg[WPT];
+    auto load_w = [&](int chunk, int ky) {
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(wbase + ((long)chunk * 9 + ky * 3) * BM * CK);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[i] = src[tid + i * 256];
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int v = tid + i * 256;          // vector index inside [3][BM][32] (4 vectors per row)
+            const int row = v >> 2, q = v & 3;    // row = kx*BM + m
+            *reinterpret_cast<u32x4_t*>(wts + row * LD + q * 8) = wreg[i];
+        }
+    };
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * CK;
+        load_w(chunk, 0);
+        // ---- stage the input patch of this chunk: [pixel][channel], two channels per thread per pass ----
+        // element id = cpair * NPIX + pix  -> lanes walk pixels (coalesced rows of 34), 16 channel pairs
+        for (int id = tid; id < (CK / 2) * NPIX; id += 256) {
+            const int cp = id / NPIX, pix = id - cp * NPIX;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const int c = c0 + 2 * cp;
+            float v0 = 0.f, v1 = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const float* p = ximg + (long)c * HW + (long)iy * W + ix;
+                if (c < d.Ck) {
+                    v0 = p[0];
+                    if (d.in_scale) {
+                        v0 = fmaf(v0, d.in_scale[c], d.in_shift[c]);
+                        if (d.in_relu) v0 = fmaxf(v0, 0.f);
+                    }
+                }
+                if (c + 1 < d.Ck) {
+                    v1 = p[HW];
+                    if (d.in_scale) {
+                        v1 = fmaf(v1, d.in_scale[c + 1], d.in_shift[c + 1]);
+                        if (d.in_relu) v1 = fmaxf(v1, 0.f);
+                    }
+                }
+            }
+            *reinterpret_cast<unsigned int*>(patch + pix * LD + 2 * cp) = gd_pack_bf2(v0, v1);
+        }
+        for (int ky = 0; ky < 3; ++ky) {
+            store_w();
+            __syncthreads();                       // weights of this kernel row (and, for ky = 0, the patch) visible
+            if (ky < 2) load_w(chunk, ky + 1);     // next row's weights fly under the MFMAs
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int ks = 0; ks < CK / 16; ++ks) {
+                    bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = *reinterpret_cast<const bf16x8_t*>(wts + (kx * BM + wm * TM * 32 + i * 32 + r) * LD +
+                                                                  ks * 16 + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + ((wn * TN + j + ky) * PW + r + kx) * LD +
+                                                                  ks * 16 + 8 * h);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8_native_t, fa[i]), __builtin_bit_cast(bf16x8_native_t, fb[j]),
+                                acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();                       // all reads of wts (and after ky = 2 of the patch) are done
+        }
+    }
+
+    // ---- epilogue (same contract as gd_conv2d: alpha, bias, residual, activation, accumulate) ----
+    const float alpha = d.alpha ? *d.alpha : 1.f;
+    const int ox = x0 + r;
+    if (ox < W) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int oy = y0 + wn * TN + j;
+            if (oy >= H) continue;
+            const long pn = (long)oy * W + ox;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mt * BM + wm * TM * 32 + i * 32 + acc_row(e, h);
+                    if (m >= d.M) continue;
+                    float v = acc[i][j][e] * alpha;
+                    if (d.bias) v += d.bias[m];
+                    if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HW + pn];
+                    if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
+                    float* yp = reinterpret_cast<float*>(d.y) + (long)b * d.y_bs + (long)m * HW + pn;
+                    if (d.accumulate) v += *yp;
+                    *yp = v;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gd_conv3x3_ws_bytes(int M, int Ck) {
+    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const long mtiles = (M + bm - 1) / bm, nchunks = (Ck + CK - 1) / CK;
+    return (size_t)(mtiles * bm * nchunks * CK * 9 * 2);
+}
+
+// returns 1 when the descriptor is served by this kernel, 0 when the caller should use the generic one
+extern "C" int gd_conv3x3_eligible(const gd_conv_desc* d) {
+    return d && d->ks == 3 && d->stride == 1 && d->pad == 1 && d->out_layout == 0 && !d->out_bf16 &&
+           d->precision == GD_PREC_BF16 && d->a_bs == 0 && d->Hi == d->Ho && d->Wi == d->Wo &&
+           (d->Mstore == 0 || d->Mstore == d->M);
+}
+
+extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, void* stream) {
+    GD_CHECK_ARG(dp && ws, "gd_conv3x3: null argument");
+    GD_CHECK_ARG(gd_conv3x3_eligible(dp), "gd_conv3x3: descriptor not eligible (needs 3x3, stride 1, pad 1, bf16, fp32 NCHW out)");
+    const gd_conv_desc& d = *dp;
+    GD_CHECK_ARG(d.B > 0 && d.B <= 65535 && d.M > 0 && d.Ck > 0 && d.Hi > 0 && d.Wi > 0, "gd_conv3x3: bad sizes");
+    GD_CHECK_ARG(d.a && d.x && d.y, "gd_conv3x3: null tensor");
+    GD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr), "gd_conv3x3: in_scale/in_shift must come together");
+    GD_CHECK_ARG(ws_bytes >= gd_conv3x3_ws_bytes(d.M, d.Ck), "gd_conv3x3: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int bm = (d.M <= 64 || (d.M % 128 != 0 && d.M % 128 <= 64)) ? 64 : 128;
+    const int mtiles = (d.M + bm - 1) / bm, nchunks = (d.Ck + CK - 1) / CK;
+    const long total = (long)mtiles * nchunks * 9 * bm * CK;
+    {
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, d.a, d.a_sm, d.a_sc, d.a_st, d.M, d.Ck,
+                           d.transposed ? 1 : 0, bm, nchunks, (unsigned short*)ws, total);
+    }
+    constexpr int TH = 8;
+    const int tiles_x = (d.Wi + TW - 1) / TW, tiles_y = (d.Hi + TH - 1) / TH;
+    GD_CHECK_ARG((long)tiles_x * tiles_y < (1L << 31), "gd_conv3x3: image too large");
+    dim3 grid(tiles_x * tiles_y, mtiles, d.B);
+    if (bm == 64)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<64, TH>), grid, dim3(256), 0, s, d, (const unsigned short*)ws, tiles_x, nchunks);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<128, TH>), grid, dim3(256), 0, s, d, (const unsigned short*)ws, tiles_x, nchunks);
+    GD_LAUNCH_CHECK();
+    return 0;
+}

@@ -65,6 +65,9 @@ def lib():
     return L.load()
 
 
+USE_CONV3X3_FAST = True   # route eligible 3x3/s1/p1 bf16 convs to the LDS-patch kernel (tests flip it to A/B)
+
+
 # ---- optional HIP-event brackets around the hot kernels (bench.py's live roofline measurement) -------------
 PROFILE_ON = False
 PROFILE: list = []   # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
@@ -123,6 +126,11 @@ def conv_nn(*, B: int, M: int, Ck: int, ks: int, stride: int, pad: int, transpos
     d.out_layout, d.out_bf16, d.ldo = out_layout, int(out_bf16), ldo
     d.alpha, d.bias, d.res, d.res_bs = _ptr(alpha), _ptr(bias), _ptr(res), res_bs
     d.act, d.accumulate, d.precision = act, int(accumulate), precision
+    if USE_CONV3X3_FAST and lib().gd_conv3x3_eligible(C.byref(d)):
+        nbytes = int(lib().gd_conv3x3_ws_bytes(M, Ck))
+        ws = torch.empty(nbytes // 2, device=x.device, dtype=torch.bfloat16)   # packed bf16 weights
+        L.check(lib().gd_conv3x3(C.byref(d), _ptr(ws), nbytes, _stream()), "gd_conv3x3")
+        return
     L.check(lib().gd_conv2d(C.byref(d), _stream()), "gd_conv2d")
 
 

@@ -73,6 +73,14 @@ typedef struct gd_conv_desc {
 } gd_conv_desc;
 int gd_conv2d(const gd_conv_desc* d, void* stream);
 
+/* 3x3 / stride 1 / pad 1 fast path (bf16 MFMA): the input patch of a TH x 32 pixel tile is staged once in LDS
+ * and reused by all nine taps; weights are pre-packed into `ws` (gd_conv3x3_ws_bytes(M, Ck) bytes, caller
+ * owned).  Same descriptor and epilogue contract as gd_conv2d; serves the forward conv (transposed = 0) and
+ * the data gradient (transposed = 1).  gd_conv3x3_eligible() tells whether a descriptor qualifies. */
+size_t gd_conv3x3_ws_bytes(int M, int Ck);
+int gd_conv3x3_eligible(const gd_conv_desc* d);
+int gd_conv3x3(const gd_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * "NT" GEMM with the long reduction split over workgroups:
  *     C[b][m][n] (+)= alpha * sum_k A[b][m][k] * B~[b][n][k]        (k contiguous in both)

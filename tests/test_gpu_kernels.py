@@ -277,3 +277,34 @@ def test_transpose_and_pack(gd):
     ref = torch.zeros(2, 32, 128); ref[:, :23, :70] = s
     assert torch.equal(plain.float().cpu(), ref.to(torch.bfloat16).float())
     assert torch.equal(tr.float().cpu(), ref.transpose(1, 2).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("shape", [(2, 72, 24, 64, 184), (1, 368, 16, 32, 184), (1, 64, 40, 96, 64), (2, 3, 33, 70, 64)])
+def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
+    """the LDS-patch 3x3 kernel against the generic implicit-GEMM kernel (same bf16 operands -> agreement to
+    fp32 accumulation order) and against the oracle; forward with fused BN-affine+ReLU prologue, bias, ReLU,
+    and the data gradient."""
+    ops, K = _ops()
+    from gan_danet_amd import _lib as L
+    B, Cin, H, W, Cout = shape
+    x = bf16_round(seeded((B, Cin, H, W), 61)).to(DEV)
+    w = bf16_round(seeded((Cout, Cin, 3, 3), 62, 1.0 / math.sqrt(Cin * 9))).to(DEV)
+    bias = seeded((Cout,), 63, 0.1).to(DEV)
+    sc, sh = (seeded((Cin,), 64).abs() * 0.5 + 0.75).to(DEV), seeded((Cin,), 65, 0.2).to(DEV)
+    outs = {}
+    for fast in (True, False):
+        K.USE_CONV3X3_FAST = fast
+        try:
+            y = K.conv2d_fwd(x, w, bias, 1, 1, L.PREC_BF16, act=ops.ACT_RELU, in_scale=sc, in_shift=sh, in_relu=True)
+            dy = bf16_round(seeded((B, Cout, H, W), 66)).to(DEV)
+            dx = K.conv2d_dgrad(dy, w, (H, W), 1, 1, L.PREC_BF16)
+        finally:
+            K.USE_CONV3X3_FAST = True
+        outs[fast] = (y, dx)
+    assert_close(outs[True][0], outs[False][0].cpu(), 1e-5, "patch vs generic fwd")
+    assert_close(outs[True][1], outs[False][1].cpu(), 1e-5, "patch vs generic dgrad")
+    xin = F.relu(x.cpu() * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+    yr = F.relu(F.conv2d(xin, w.cpu(), bias.cpu(), padding=1))
+    assert_close(outs[True][0], yr, BF16_TOL, "patch fwd vs oracle")
+    dxr = torch.nn.grad.conv2d_input((B, Cin, H, W), w.cpu(), dy.cpu(), padding=1)
+    assert_close(outs[True][1], dxr, BF16_TOL, "patch dgrad vs oracle", rell2)
