@@ -19,9 +19,15 @@ __device__ __forceinline__ unsigned short gd_f2bf(float f) {
 __device__ __forceinline__ float gd_bf2f(unsigned short h) {
     return __builtin_bit_cast(float, ((unsigned int)h) << 16);
 }
+typedef float gd_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 gd_bf16x2_t __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (lo in bits 0..15): a vector convert lowers to ONE v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned int gd_pack_bf2(float lo, float hi) {
-    return (unsigned int)gd_f2bf(lo) | ((unsigned int)gd_f2bf(hi) << 16);
+    const gd_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, gd_bf16x2_t));
 }
+// raw v_exp_f32 (2^x) without the denormal-range fix-up sequence exp2f() expands to; callers pass x <= ~0
+__device__ __forceinline__ float gd_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- wave / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float gd_wave_sum(float v) {

@@ -139,22 +139,23 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
                 sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
             }
         }
-        // ---- online softmax (log2 domain) ----
-        const bool tail = (t + 1) * F_KT > N;
-        float mloc = -1e30f;
+        // ---- online softmax (log2 domain): m, l track max and sum of s*log2(e) ----
+        if ((t + 1) * F_KT > N) {   // wave-uniform: only the last tile masks padded keys
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
+        }
+        float mloc = sacc[0][0];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float sv = sacc[sub][e] * LOG2E;
-                if (tail && (t * F_KT + sub * 32 + acc_row(e, h)) >= N) sv = -1e30f;
-                sacc[sub][e] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
         const float m_new = fmaxf(m, mloc);
         if (__any(m_new > m)) {  // wave-uniform: skip the O rescale when no query's max moved
-            const float alpha = exp2f(m - m_new);
+            const float alpha = gd_exp2_fast(m - m_new);
             l *= alpha;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -163,11 +164,12 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
             m = m_new;
         }
         float lsum = 0.f;
+        const float neg_m = -m;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f(sacc[sub][e] - m);
+                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
                 sacc[sub][e] = p;
                 lsum += p;
             }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const bool ok = key_ok && (i0 + acc_row(e, h)) < N;
-            const float p = ok ? exp2f(sacc[e] * LOG2E) : 0.f;
+            const float p = ok ? gd_exp2_fast(sacc[e] * LOG2E) : 0.f;
             sacc[e] = p;
             dpacc[e] = p * dpacc[e];  // dS
         }
@@ -385,6 +387,188 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
         for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+}
+
+// =====================================================================================================
+// backward, part 1b: dK^T / dV^T with the channels split over wave pairs (even CT).
+//   8 waves = 4 key groups x 2 channel halves.  Both waves of a pair compute S; each accumulates dP over ITS
+//   half of the channels, the two partial dP tiles are exchanged through LDS, then each wave updates dV^T for
+//   its half of the channel tiles and one of the two k-steps of dK^T.  The accumulators of a wave shrink to
+//   (CT/2 + 1) tiles, so 8 waves (2 per SIMD) fit the 512-register file even at Cp = 192.
+// =====================================================================================================
+template <int CT>
+__global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
+    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const unsigned short* __restrict__ don,
+    const float* __restrict__ lse, const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn,
+    float* __restrict__ dv) {
+    static_assert(CT % 2 == 0, "channel tiles are split in two halves");
+    constexpr int CP = CT * 32;
+    constexpr int HT = CT / 2;                     // channel tiles per wave
+    constexpr int NT = 512;
+    constexpr int DLD = CP + 8;
+    constexpr int NCHUNK = 256 + 256 * CT;
+    constexpr int NPRE = (NCHUNK + NT - 1) / NT;
+    constexpr bool RAGGED = (NCHUNK % NT) != 0;    // last pass only covers part of the threads
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
+    __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
+    __shared__ float Xs[8 * 16 * 64];              // partial-dP exchange: [wave][register][lane]
+    __shared__ float Ls[32], Ds[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int kg = wave >> 1, half = wave & 1;
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * 128 + kg * 32;
+    const long nb = (long)b * Npad;
+
+    bf16x8_t kfB[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
+    bf16x8_t vfB[CT];   // this wave's half of the channel k-steps of dP = dO V^T
+#pragma unroll
+    for (int s = 0; s < CT; ++s)
+        vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + (half * CT + s) * 16 + 8 * h);
+
+    f32x16_t dvacc[HT], dkacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[e] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
+
+    const bool key_ok = (j0 + r) < N;
+    const int nqt = (N + 31) / 32;
+
+    // ---- staging plan, fixed per thread: source pointer at tile 0, elements to advance per tile, LDS slot ----
+    const unsigned short* src[NPRE];
+    int step[NPRE];
+    unsigned short* dst[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        int c = tid + k * NT;
+        if (RAGGED && k == NPRE - 1 && c >= NCHUNK) c = 0;   // parked on a valid chunk, never stored
+        if (c < 128) {
+            src[k] = qt + (nb + (c >> 2)) * 32 + (c & 3) * 8;  step[k] = 32 * 32;
+            dst[k] = Qs + (c >> 2) * B_QLD + (c & 3) * 8;
+        } else if (c < 256) {
+            const int c2 = c - 128;
+            src[k] = qn + ((long)b * 32 + (c2 >> 2)) * Npad + (c2 & 3) * 8;  step[k] = 32;
+            dst[k] = QTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8;
+        } else if (c < 256 + 128 * CT) {
+            const int c2 = c - 256;
+            const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
+            src[k] = dot_ + (nb + i) * CP + ch * 8;  step[k] = 32 * CP;
+            dst[k] = dOs + i * DLD + ch * 8;
+        } else {
+            const int c2 = c - 256 - 128 * CT;
+            src[k] = don + ((long)b * CP + (c2 >> 2)) * Npad + (c2 & 3) * 8;  step[k] = 32;
+            dst[k] = dOTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8;
+        }
+    }
+    const bool last_ok = !RAGGED || (tid + (NPRE - 1) * NT) < NCHUNK;
+
+    u32x4_t pre[NPRE];
+    float pre_s = 0.f;
+    auto load_tile = [&](int qtile) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
+        if (tid < 64) {
+            const int i = qtile * 32 + (tid & 31);
+            pre_s = i < N ? (tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            if (k < NPRE - 1 || last_ok) {   // every slot is 8-byte aligned: two 8-byte stores serve all four regions
+                u32x2_t* d2 = reinterpret_cast<u32x2_t*>(dst[k]);
+                d2[0] = u32x2_t{pre[k].x, pre[k].y};
+                d2[1] = u32x2_t{pre[k].z, pre[k].w};
+            }
+        }
+        if (tid < 32) Ls[tid] = pre_s;
+        else if (tid < 64) Ds[tid - 32] = pre_s;
+    };
+
+    float* xmine = Xs + wave * (16 * 64) + lane;
+    const float* xpart = Xs + (wave ^ 1) * (16 * 64) + lane;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int qtile = 0; qtile < nqt; ++qtile) {
+        const int i0 = qtile * 32;
+        if (qtile + 1 < nqt) load_tile(qtile + 1);
+
+        f32x16_t sacc, dpacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = -Ls[acc_row(e, h)];
+            dpacc[e] = half == 0 ? -Ds[acc_row(e, h)] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
+            sacc = mfma_bf16(qa, kfB[s], sacc);
+        }
+#pragma unroll
+        for (int s = 0; s < CT; ++s) {
+            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + (half * CT + s) * 16 + 8 * h);
+            dpacc = mfma_bf16(da, vfB[s], dpacc);
+        }
+        // ---- exchange the partial dP tiles inside the wave pair ----
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xmine[e * 64] = dpacc[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpacc[e] += xpart[e * 64];
+
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool ok = key_ok && (i0 + acc_row(e, h)) < N;
+            const float p = ok ? gd_exp2_fast(sacc[e] * LOG2E) : 0.f;
+            sacc[e] = p;
+            dpacc[e] = p * dpacc[e];  // dS
+        }
+        bf16x8_t pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pf[s] = pack_frag(sacc, s);
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct) {
+            const unsigned short* row = dOTs + ((half * HT + ct) * 32 + r) * B_TLD;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_perm_frag(row, s * 16, h), pf[s], dvacc[ct]);
+        }
+        // dK^T: this wave takes k-step `half` (queries 16*half .. 16*half+15 of the tile); the partner the other
+        dkacc = mfma_bf16(read_perm_frag(QTs + r * B_TLD, half * 16, h),
+                          half == 0 ? pack_frag(dpacc, 0) : pack_frag(dpacc, 1), dkacc);
+        __syncthreads();  // tile and exchange buffer fully consumed
+        if (qtile + 1 < nqt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    const int j = j0 + r;
+#pragma unroll
+    for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            dv[((long)b * CP + (half * HT + ct) * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
+    // dK^T = sum of the pair's two k-step halves
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xmine[e * 64] = dkacc[e];
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e] + xpart[e * 64];
+    }
 }
 
 // =====================================================================================================
@@ -478,9 +662,13 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float p = exp2f(fmaf(sacc[e], LOG2E, nlse));
-                if (tail && (t * Q_KT + sub * 32 + acc_row(e, h)) >= N) p = 0.f;
+                const float p = gd_exp2_fast(fmaf(sacc[e], LOG2E, nlse));
                 dpacc[e] = p * dpacc[e];  // dS^T
+            }
+            if (tail) {   // wave-uniform: padded keys of the last tile contribute nothing
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((t * Q_KT + sub * 32 + acc_row(e, h)) >= N) dpacc[e] = 0.f;
             }
             const unsigned short* krow = KNs + r * F_VLD;
 #pragma unroll
@@ -534,16 +722,16 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, 
     hipStream_t s = (hipStream_t)stream;
     // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
     // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
-    if (Cp <= 160) {
+    if (Cp == 192) {   // even tile count too large for one wave's registers: channel halves split over wave pairs
+        hipLaunchKernelGGL((pam_bwd_dkv_split_kernel<6>), dim3(Npad / 128, B), dim3(512), 0, s, (const unsigned short*)qt,
+                           (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
+                           (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);
+    } else {
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0, s,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)qn, (const unsigned short*)vt,
                                                      (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
                                                      N, Npad, dkn, dv));
-    } else {
-        hipLaunchKernelGGL((pam_bwd_dkv_kernel<6, 4>), dim3(Npad / 128, B), dim3(256), 0, s, (const unsigned short*)qt,
-                           (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
-                           (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);
     }
     PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
                                                  (const unsigned short*)qt, (const unsigned short*)kt,

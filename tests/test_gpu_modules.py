@@ -259,3 +259,32 @@ def test_perceptual_loss_vs_oracle(gd):
         lg.backward()
     assert_close(lg, lo, 1e-4, "perceptual value")
     assert_close(ag.grad, ar.grad, 2e-3, "perceptual grad", rell2)
+
+
+@pytest.mark.parametrize("c,hw", [(184, 16), (176, 24), (64, 32)])
+def test_pam_fused_other_widths_vs_oracle(gd, c, hw):
+    """the widths the generator really uses (176/184 -> Cp = 192: channel-split dK/dV kernel; N not a multiple
+    of 256 -> padded keys/queries) against the CPU oracle on bf16-rounded inputs"""
+    from gan_danet_amd.generator import PAMModule
+    from oracle import modules as OM
+    mo = OM.PAMModule(c)
+    fill_module(mo)
+    with torch.no_grad():
+        mo.gamma.fill_(0.7)
+    x = bf16_round(seeded((2, c, hw, hw), 81))
+    go = bf16_round(seeded((2, c, hw, hw), 82))
+    xo = x.clone().requires_grad_(True)
+    yo = mo(xo)
+    yo.backward(go)
+    m = PAMModule(c)
+    m.load_state_dict(mo.state_dict())
+    m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    with gd.precision("bf16"):
+        y = m(xg)
+        y.backward(go.to(DEV))
+    assert_close(y, yo, 2e-2, "y")
+    assert_close(xg.grad, xo.grad, 5e-2, "dx", rell2)
+    po, pg = dict(mo.named_parameters()), dict(m.named_parameters())
+    for n in ("query.weight", "key.weight", "value.weight", "value.bias", "query.bias", "gamma"):
+        assert_close(pg[n].grad, po[n].grad, 5e-2, n, rell2)
