@@ -225,3 +225,195 @@ extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, voi
     GD_LAUNCH_CHECK();
     return 0;
 }
+
+// =====================================================================================================
+// weight gradient of the 3x3 / stride 1 / pad 1 convolution
+//   dW[co][ci][tap] = sum_{b,y,x} dY[b][co][y][x] * X~[b][ci][y+ky-1][x+kx-1]
+// GEMM view per tap: M = co, N = ci, K = pixels.  A workgroup owns BM = 32*NW output channels x one 32-channel
+// chunk of ci x all nine taps (wave w holds the nine 32x32 accumulators of m-tile w) and walks a share of the
+// (image, 4x32-pixel tile) list.  Per tile it stages dY as [co][pixel] (pixel-contiguous like NCHW: the A
+// fragment is one 16-byte read) and the haloed input patch as [pixel][ci] -- the same image the forward kernel
+// uses -- and takes the B fragments (k = pixel, n = ci) with ds_read_b64_tr_b16, the LDS transpose read, so the
+// nine taps are nine shifted reads of one staged patch.  Partial sums of the splits are combined with fp32
+// atomics into the (small) weight gradient.
+// =====================================================================================================
+namespace {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+constexpr int WTH = 4;                 // tile rows
+constexpr int WPH = WTH + 2;
+constexpr int WNPIX = WPH * PW;        // 204 patch pixels
+constexpr int DYLD = WTH * TW + 8;     // dY rows: 128 pixels + 8 pad (272 B): conflict-free 16-byte reads
+
+struct WgradArgs {
+    const float* dy; long dy_bs;
+    const float* x; long x_bs;
+    const float* in_scale; const float* in_shift; int in_relu;
+    float* dw;
+    int B, M, Ck, H, W;
+    int tiles_x, tiles_y, tiles_per_split;
+};
+
+__device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    constexpr int BM = 32 * NW, NT = 64 * NW;
+    __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
+    __shared__ __attribute__((aligned(16))) unsigned short patch[WNPIX * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int c0 = blockIdx.x * CK;
+    const int m0 = blockIdx.y * BM;
+    const long HW = (long)a.H * a.W;
+    const int ntiles = a.B * a.tiles_y * a.tiles_x;
+    const int t_begin = blockIdx.z * a.tiles_per_split;
+    const int t_end = min(ntiles, t_begin + a.tiles_per_split);
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // transpose-read lane roles: group of 16 lanes = one 4(k) x 16(n) block; lane 4q+pp supplies row q, cols 4pp..
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
+    const bool vec_ok = (a.W % 4) == 0;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / (a.tiles_y * a.tiles_x);
+        const int rem = t - b * (a.tiles_y * a.tiles_x);
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+        const int y0 = ty_ * WTH, x0 = tx_ * TW;
+        const float* dyb = a.dy + (long)b * a.dy_bs;
+        const float* xb = a.x + (long)b * a.x_bs;
+
+        // ---- dY tile -> [co][pixel] bf16 : 4-pixel vectors, BM*32 of them ----
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int idx = tid + k * NT;
+            const int m = idx >> 5, v = idx & 31;
+            const int yy = y0 + (v >> 3), xx = x0 + (v & 7) * 4;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + m < a.M && yy < a.H) {
+                const float* p = dyb + (long)(m0 + m) * HW + (long)yy * a.W + xx;
+                if (vec_ok && xx + 3 < a.W) {
+                    f = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (xx + 0 < a.W) f.x = p[0];
+                    if (xx + 1 < a.W) f.y = p[1];
+                    if (xx + 2 < a.W) f.z = p[2];
+                    if (xx + 3 < a.W) f.w = p[3];
+                }
+            }
+            uint2 w;
+            w.x = gd_pack_bf2(f.x, f.y);
+            w.y = gd_pack_bf2(f.z, f.w);
+            *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
+        }
+        // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU), two channels per thread per pass ----
+        for (int id = tid; id < (CK / 2) * WNPIX; id += NT) {
+            const int cp = id / WNPIX, pix = id - cp * WNPIX;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const int c = c0 + 2 * cp;
+            float v0 = 0.f, v1 = 0.f;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                const float* p = xb + (long)c * HW + (long)iy * a.W + ix;
+                if (c < a.Ck) {
+                    v0 = p[0];
+                    if (a.in_scale) {
+                        v0 = fmaf(v0, a.in_scale[c], a.in_shift[c]);
+                        if (a.in_relu) v0 = fmaxf(v0, 0.f);
+                    }
+                }
+                if (c + 1 < a.Ck) {
+                    v1 = p[HW];
+                    if (a.in_scale) {
+                        v1 = fmaf(v1, a.in_scale[c + 1], a.in_shift[c + 1]);
+                        if (a.in_relu) v1 = fmaxf(v1, 0.f);
+                    }
+                }
+            }
+            *reinterpret_cast<unsigned int*>(patch + pix * LD + 2 * cp) = gd_pack_bf2(v0, v1);
+        }
+        __syncthreads();
+
+        // ---- 8 k-steps of 16 pixels x 9 taps ----
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {
+            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(dys + (wave * 32 + r) * DYLD + 16 * s + 8 * h);
+            const int prow = s >> 1, pcol = (s & 1) * 16 + 8 * h + tq;   // tile-local pixel of this lane's block row
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const unsigned short* p0 = patch + ((prow + ky) * PW + pcol + kx) * LD + 16 * tg + 4 * tp;
+                    const s16x4_t lo = lds_tr_read(p0);            // pixels +0..3
+                    const s16x4_t hi = lds_tr_read(p0 + 4 * LD);   // pixels +4..7
+                    const bf16x8_t fb = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_native_t, fa), __builtin_bit_cast(bf16x8_native_t, fb),
+                        acc[ky * 3 + kx], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- combine: dW[co][ci][tap] += acc ----
+    const int ci = c0 + r;
+    if (ci < a.Ck) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + wave * 32 + acc_row(e, h);
+                if (co < a.M) atomicAdd(a.dw + ((long)co * a.Ck + ci) * 9 + t, acc[t][e]);
+            }
+    }
+}
+
+}  // namespace
+
+// dw (Cout, Cin, 3, 3) fp32 is overwritten.  Same input-transform contract as gd_conv2d.
+extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, const float* in_scale,
+                                const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, float* dw,
+                                void* stream) {
+    GD_CHECK_ARG(dy && x && dw, "gd_conv3x3_wgrad: null pointer");
+    GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0, "gd_conv3x3_wgrad: bad sizes");
+    GD_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gd_conv3x3_wgrad: in_scale/in_shift must come together");
+    hipStream_t s = (hipStream_t)stream;
+    GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) == hipSuccess, "gd_conv3x3_wgrad: memset failed");
+    WgradArgs a;
+    a.dy = dy; a.dy_bs = dy_bs; a.x = x; a.x_bs = x_bs;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+    a.dw = dw; a.B = B; a.M = Cout; a.Ck = Cin; a.H = H; a.W = W;
+    a.tiles_x = (W + TW - 1) / TW;
+    a.tiles_y = (H + WTH - 1) / WTH;
+    const long ntiles = (long)B * a.tiles_x * a.tiles_y;
+    GD_CHECK_ARG(ntiles < (1L << 31), "gd_conv3x3_wgrad: too many tiles");
+    // m-tiles per workgroup: 2, 4 or 6 waves, whichever pads Cout least (ties -> the larger block)
+    int best_nw = 2;
+    long best_pad = -1;
+    for (int nw : {2, 4, 6}) {
+        const long bm = 32L * nw, pad = ((Cout + bm - 1) / bm) * bm;
+        if (best_pad < 0 || pad <= best_pad) { best_pad = pad; best_nw = nw; }
+    }
+    const int bm = 32 * best_nw;
+    const int mblocks = (Cout + bm - 1) / bm, chunks = (Cin + CK - 1) / CK;
+    long splits = 1024 / ((long)mblocks * chunks);
+    if (splits < 1) splits = 1;
+    if (splits > ntiles) splits = ntiles;
+    if (splits > 65535) splits = 65535;
+    a.tiles_per_split = (int)((ntiles + splits - 1) / splits);
+    splits = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    dim3 grid(chunks, mblocks, (unsigned)splits);
+    if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2>), grid, dim3(128), 0, s, a);
+    else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6>), grid, dim3(384), 0, s, a);
+    GD_LAUNCH_CHECK();
+    return 0;
+}

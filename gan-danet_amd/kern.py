@@ -202,6 +202,10 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
     B, Cout, Ho, Wo = dy.shape
     _, Cin, Hi, Wi = x.shape
     dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
+    if USE_CONV3X3_FAST and k == 3 and stride == 1 and pad == 1 and precision == L.PREC_BF16:
+        L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift), int(in_relu), B,
+                                       Cout, Cin, Hi, Wi, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+        return dw
     gemm_nt(B=1, M=Cout, N=Cin * k * k, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0,
             b_ss=xbs, ldb=0, c=dw, c_bs=0, ldc=Cin * k * k, precision=precision,
             im2col=(k, stride, pad, Hi, Wi, Ho, Wo), in_scale=in_scale, in_shift=in_shift, in_relu=in_relu)

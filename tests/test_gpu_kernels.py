@@ -298,9 +298,11 @@ def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
             y = K.conv2d_fwd(x, w, bias, 1, 1, L.PREC_BF16, act=ops.ACT_RELU, in_scale=sc, in_shift=sh, in_relu=True)
             dy = bf16_round(seeded((B, Cout, H, W), 66)).to(DEV)
             dx = K.conv2d_dgrad(dy, w, (H, W), 1, 1, L.PREC_BF16)
+            dw = K.conv2d_wgrad(dy, x, 3, 1, 1, L.PREC_BF16, in_scale=sc, in_shift=sh, in_relu=True)
         finally:
             K.USE_CONV3X3_FAST = True
-        outs[fast] = (y, dx)
+        outs[fast] = (y, dx, dw)
+    assert_close(outs[True][2], outs[False][2].cpu(), 1e-4, "patch vs generic wgrad")
     assert_close(outs[True][0], outs[False][0].cpu(), 1e-5, "patch vs generic fwd")
     assert_close(outs[True][1], outs[False][1].cpu(), 1e-5, "patch vs generic dgrad")
     xin = F.relu(x.cpu() * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
@@ -308,3 +310,5 @@ def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
     assert_close(outs[True][0], yr, BF16_TOL, "patch fwd vs oracle")
     dxr = torch.nn.grad.conv2d_input((B, Cin, H, W), w.cpu(), dy.cpu(), padding=1)
     assert_close(outs[True][1], dxr, BF16_TOL, "patch dgrad vs oracle", rell2)
+    dwr = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, 3, 3), dy.cpu(), padding=1)
+    assert_close(outs[True][2], dwr, BF16_TOL, "patch wgrad vs oracle", rell2)
