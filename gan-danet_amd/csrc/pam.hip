@@ -15,6 +15,8 @@
 //   sweeps the queries in 32-row tiles; S and dP are computed with the key on the lane, so P and dS are
 //   directly the B operands of dV^T += dO^T P and dK^T += Q^T dS; only dS crosses LDS (for dQ += dS K, which is
 //   accumulated across workgroups with fp32 atomics in 128-byte row segments).
+#include <stdlib.h>
+
 #include "common.h"
 #include "tile_mma.h"
 #include "../../include/gandanet.h"
@@ -226,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
 constexpr int B_TLD = 36;   // transposed tiles rows [..][32 i] (72 B): 8-B reads, conflict free
 
-template <int CT, int NW>
+// VLDS = true keeps this workgroup's V rows in LDS instead of 8*CT registers per lane (Cp = 192 would not fit 256)
+template <int CT, int NW, bool VLDS = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const unsigned short* __restrict__ don,
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vls[VLDS ? NW * 32 * DLD : 8];   // V rows [key][CP c]
     __shared__ float Ls[32], Ds[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,10 +257,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
     bf16x8_t kfB[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
-    bf16x8_t vfB[2 * CT];
+    bf16x8_t vfB[VLDS ? 1 : 2 * CT];
+    if constexpr (VLDS) {
+        // the workgroup's NW*32 keys x CP channels, once: 16-byte chunks, rows padded to DLD (conflict-free reads)
+        const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * (NW * 32)) * CP;
+        for (int c = tid; c < NW * 32 * (CP / 8); c += NT) {
+            const int row = c / (CP / 8), ch = c - row * (CP / 8);
+            *reinterpret_cast<u32x4_t*>(Vls + row * DLD + ch * 8) =
+                *reinterpret_cast<const u32x4_t*>(vsrc + (long)row * CP + ch * 8);
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < 2 * CT; ++s)
-        vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + s * 16 + 8 * h);
+        for (int s = 0; s < 2 * CT; ++s)
+            vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + s * 16 + 8 * h);
+    }
 
     f32x16_t dvacc[CT], dkacc;
 #pragma unroll
@@ -345,7 +359,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
 #pragma unroll
         for (int s = 0; s < 2 * CT; ++s) {
             const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
-            dpacc = mfma_bf16(da, vfB[s], dpacc);
+            if constexpr (VLDS) {
+                const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vls + (wave * 32 + r) * DLD + s * 16 + 8 * h);
+                dpacc = mfma_bf16(da, vb, dpacc);
+            } else {
+                dpacc = mfma_bf16(da, vfB[s], dpacc);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -722,10 +741,16 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, 
     hipStream_t s = (hipStream_t)stream;
     // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
     // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
-    if (Cp == 192) {   // even tile count too large for one wave's registers: channel halves split over wave pairs
+    static const int split_env = getenv("GD_PAM_DKV_SPLIT") ? atoi(getenv("GD_PAM_DKV_SPLIT")) : 0;
+    if (Cp == 192 && split_env) {   // alternative for Cp = 192: channel halves split over wave pairs (A/B switch)
         hipLaunchKernelGGL((pam_bwd_dkv_split_kernel<6>), dim3(Npad / 128, B), dim3(512), 0, s, (const unsigned short*)qt,
                            (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
                            (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);
+    } else if (Cp == 192) {         // 12 V fragments per lane do not fit beside 7 accumulator tiles: V rows live in LDS
+        hipLaunchKernelGGL((pam_bwd_dkv_kernel<6, 8, true>), dim3(Npad / 256, B), dim3(512), 0, s,
+                           (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)qn,
+                           (const unsigned short*)vt, (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
+                           N, Npad, dkn, dv);
     } else {
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0, s,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
