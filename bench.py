@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-perceptual", action="store_true", help="exploration only; the reported config has it on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a one-GPU box, all ranks on cuda:0)")
     return ap.parse_args()
 
 
@@ -88,11 +90,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu_rehearsal = args.backend != "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if one_gpu_rehearsal:
+            dist.init_process_group(args.backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if (world > 1 and not one_gpu_rehearsal) else 0)
     torch.cuda.set_device(dev)
 
     import gan_danet_amd as gd

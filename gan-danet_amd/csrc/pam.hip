@@ -223,6 +223,174 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
 }
 
 // =====================================================================================================
+// forward, LDS-DMA variant: K/V tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers,
+// no store phase) into a 2-deep ring; one barrier per key tile.  A DMA wave-instruction writes 64 lanes x 16 B
+// = 1 KiB of CONTIGUOUS LDS, so the padded row layouts are kept by letting one lane in five (K rows: 4 data
+// chunks + 1 pad) / nine (V rows: 8 + 1) fetch a duplicate chunk into the pad slot.
+// =====================================================================================================
+constexpr int D_KROWCH = 5;                 // 16-byte chunks per K row (80 B)
+constexpr int D_VROWCH = 9;                 // 16-byte chunks per V row (144 B)
+constexpr int D_VLD = D_VROWCH * 8;         // 72 elements
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned short* __restrict__ qt,
+                                                            const unsigned short* __restrict__ kt,
+                                                            const unsigned short* __restrict__ v, int N, int Npad, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ x,
+                                                            long x_bs, float* __restrict__ out, long out_bs,
+                                                            float* __restrict__ o_attn, float* __restrict__ lse) {
+    constexpr int CP = CT * 32;
+    constexpr int KCH = F_KT * D_KROWCH;            // 320 chunks of K
+    constexpr int NCH = KCH + CP * D_VROWCH;        // + V chunks
+    constexpr int NPIECE = (NCH + 63) / 64;         // 1-KiB DMA pieces per tile
+    constexpr int PPW = (NPIECE + 3) / 4;           // pieces per wave
+    constexpr int TILE = NPIECE * 64 * 8;           // elements per ring slot
+    __shared__ __attribute__((aligned(16))) unsigned short ring[2 * TILE];   // the ONLY LDS object (DMA + ds_read)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const unsigned short* ktb = kt + (long)b * Npad * 32;
+    const unsigned short* vb = v + (long)b * CP * Npad;
+
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
+
+    // ---- DMA plan of this lane: source of its chunk in tile 0 and elements to advance per tile ----
+    const unsigned short* src[PPW];
+    int adv[PPW];
+    bool live[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + 4 * i;
+        const int c = piece * 64 + lane;
+        live[i] = piece < NPIECE && c < NCH;
+        if (c < KCH) {
+            const int row = c / D_KROWCH, part = c - row * D_KROWCH;
+            src[i] = ktb + (long)row * 32 + (part < 4 ? part : 3) * 8;
+            adv[i] = F_KT * 32;
+        } else {
+            const int c2 = (c < NCH ? c : NCH - 1) - KCH;
+            const int row = c2 / D_VROWCH, part = c2 - row * D_VROWCH;
+            src[i] = vb + (long)row * Npad + (part < 8 ? part : 7) * 8;
+            adv[i] = F_KT;
+        }
+    }
+    auto dma_tile = [&](int t, int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (live[i]) {
+                unsigned short* dst = ring + slot * TILE + (wave + 4 * i) * 512;   // wave-uniform piece base
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)t * adv[i]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16_t o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
+    float m = -1e30f, l = 0.f;
+    const int nkt = (N + F_KT - 1) / F_KT;
+
+    dma_tile(0, 0);
+    for (int t = 0; t < nkt; ++t) {
+        // an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt wait followed by a
+        // barrier; hipcc does not emit that wait for us inside the loop (checked in the .s), so it is explicit
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // tile t landed everywhere, and slot (t+1)&1 is no longer being read
+        if (t + 1 < nkt) dma_tile(t + 1, (t + 1) & 1);
+        const unsigned short* Ks = ring + (t & 1) * TILE;
+        const unsigned short* Vs = Ks + KCH * 8;
+
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
+                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
+            }
+        }
+        if ((t + 1) * F_KT > N) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
+        }
+        float mloc = sacc[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
+        const float m_new = fmaxf(m, mloc);
+        if (__any(m_new > m)) {
+            const float alpha = gd_exp2_fast(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+            m = m_new;
+        }
+        float lsum = 0.f;
+        const float neg_m = -m;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
+                sacc[sub][e] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l += lsum;
+
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const unsigned short* vrow = Vs + (ct * 32 + r) * D_VLD;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    o[ct] = mfma_bf16(read_perm_frag(vrow, sub * 32 + s * 16, h), pf[sub][s], o[ct]);
+        }
+    }
+
+    const int qi = q0 + r;
+    if (qi < N) {
+        const float inv_l = 1.f / l;
+        const float g = *gamma;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = ct * 32 + acc_row(e, h);
+                if (c < C) {
+                    const float val = o[ct][e] * inv_l;
+                    o_attn[((long)b * C + c) * N + qi] = val;
+                    out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
+                }
+            }
+        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
+    }
+}
+
+// =====================================================================================================
 // backward, part 1: dK^T and dV^T  (key-parallel; a workgroup owns NW*32 keys and sweeps the queries)
 // =====================================================================================================
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
@@ -281,6 +449,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
         for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
 
     const bool key_ok = (j0 + r) < N;
+    const bool need_mask = (int)(blockIdx.x + 1) * (NW * 32) > N;   // uniform over the workgroup
     const int nqt = (N + 31) / 32;
 
     // ---- staging: global -> registers (prefetch, issued before the MFMAs of the previous tile) -> LDS ----
@@ -307,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
         }
         if (tid < 64) {
             const int i = i0 + (tid & 31);
-            pre_s = i < N ? (tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;   // negated once here
         }
     };
     auto store_tile = [&]() {
@@ -348,8 +517,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
         f32x16_t sacc, dpacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            sacc[e] = -Ls[acc_row(e, h)];
-            dpacc[e] = -Ds[acc_row(e, h)];
+            sacc[e] = Ls[acc_row(e, h)];    // -lse   (row constants as initial accumulators)
+            dpacc[e] = Ds[acc_row(e, h)];   // -delta
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -367,12 +536,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool ok = key_ok && (i0 + acc_row(e, h)) < N;
-            const float p = ok ? gd_exp2_fast(sacc[e] * LOG2E) : 0.f;
-            sacc[e] = p;
-            dpacc[e] = p * dpacc[e];  // dS
+        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
+        if (need_mask || i0 + 32 > N) {   // workgroup-uniform: padded keys in this block, or the ragged last query tile
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!(key_ok && (i0 + acc_row(e, h)) < N)) sacc[e] = 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpacc[e] *= sacc[e];   // dS = P (dP - delta)
         bf16x8_t pf[2], dsf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -460,6 +631,7 @@ __global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
         for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
 
     const bool key_ok = (j0 + r) < N;
+    const bool need_mask = (int)(blockIdx.x + 1) * 128 > N;
     const int nqt = (N + 31) / 32;
 
     // ---- staging plan, fixed per thread: source pointer at tile 0, elements to advance per tile, LDS slot ----
@@ -498,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
             pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
         if (tid < 64) {
             const int i = qtile * 32 + (tid & 31);
-            pre_s = i < N ? (tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;   // negated once here
         }
     };
     auto store_tile = [&]() {
@@ -528,8 +700,8 @@ __global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
         f32x16_t sacc, dpacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            sacc[e] = -Ls[acc_row(e, h)];
-            dpacc[e] = half == 0 ? -Ds[acc_row(e, h)] : 0.f;
+            sacc[e] = Ls[acc_row(e, h)];
+            dpacc[e] = half == 0 ? Ds[acc_row(e, h)] : 0.f;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -549,12 +721,14 @@ __global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
         for (int e = 0; e < 16; ++e) dpacc[e] += xpart[e * 64];
 
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const bool ok = key_ok && (i0 + acc_row(e, h)) < N;
-            const float p = ok ? gd_exp2_fast(sacc[e] * LOG2E) : 0.f;
-            sacc[e] = p;
-            dpacc[e] = p * dpacc[e];  // dS
+        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
+        if (need_mask || i0 + 32 > N) {   // workgroup-uniform: padded keys in this block, or the ragged last query tile
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!(key_ok && (i0 + acc_row(e, h)) < N)) sacc[e] = 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpacc[e] *= sacc[e];   // dS = P (dP - delta)
         bf16x8_t pf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) pf[s] = pack_frag(sacc, s);
@@ -724,10 +898,18 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 128 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
     dim3 grid(Npad / 128, B);
-    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                 (const unsigned short*)qt, (const unsigned short*)kt,
-                                                 (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn,
-                                                 lse));
+    static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 1;
+    if (dma_env) {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                     (const unsigned short*)qt, (const unsigned short*)kt,
+                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
+                                                     o_attn, lse));
+    } else {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                     (const unsigned short*)qt, (const unsigned short*)kt,
+                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
+                                                     o_attn, lse));
+    }
     GD_LAUNCH_CHECK();
     return 0;
 }
