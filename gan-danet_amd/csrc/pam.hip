@@ -765,6 +765,176 @@ __global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
 }
 
 // =====================================================================================================
+// backward, part 1c: dK^T / dV^T, transpose-read variant.  Only Q [i][d] and dO [i][c] are staged per query
+// tile; the "transposed" A operands of dV^T += dO^T P and dK^T += Q^T dS are taken from the SAME images with
+// ds_read_b64_tr_b16 (4 query rows x 16 channel columns per 16-lane group), so the q^T / dO^T copies, half of
+// the staging traffic and half of the tile LDS disappear.  V rows of the workgroup's 128 keys live in LDS.
+// 4 waves per workgroup and two independent workgroups per CU: their phases drift apart, so one's MFMA
+// segments overlap the other's softmax / staging segments instead of all eight waves meeting at one barrier.
+// =====================================================================================================
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4_t lds_tr16(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+// A fragment (row = column c of X, k = accumulator-row-ordered query index) of k-step s from X[i][c] (LDS, ld):
+// element j of lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)
+__device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld, int s, int ccol, int lane) {
+    const int li = lane & 15, hh = lane >> 5;
+    const unsigned short* p = X + (16 * s + 4 * hh + (li >> 2)) * ld + ccol + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+    const s16x4_t lo = lds_tr16(p);             // queries 16s + 4h + 0..3
+    const s16x4_t hi = lds_tr16(p + 8 * ld);    // queries 16s + 8 + 4h + 0..3
+    const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return f;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ vt,
+    const unsigned short* __restrict__ dot_, const float* __restrict__ lse, const float* __restrict__ delta, int N,
+    int Npad, float* __restrict__ dkn, float* __restrict__ dv) {
+    constexpr int CP = CT * 32;
+    constexpr int NT = 256;
+    constexpr int DLD = CP + 8;
+    constexpr int NCHUNK = 128 + 128 * CT;
+    constexpr int NPRE = (NCHUNK + NT - 1) / NT;
+    constexpr bool RAGGED = (NCHUNK % NT) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned short Vls[128 * DLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
+    __shared__ float Ls[32], Ds[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * 128 + wave * 32;
+    const long nb = (long)b * Npad;
+
+    bf16x8_t kfB[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
+    {
+        const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * 128) * CP;
+        for (int c = tid; c < 128 * (CP / 8); c += NT) {
+            const int row = c / (CP / 8), ch = c - row * (CP / 8);
+            *reinterpret_cast<u32x4_t*>(Vls + row * DLD + ch * 8) =
+                *reinterpret_cast<const u32x4_t*>(vsrc + (long)row * CP + ch * 8);
+        }
+    }
+
+    f32x16_t dvacc[CT], dkacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[e] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
+
+    const bool key_ok = (j0 + r) < N;
+    const bool need_mask = (int)(blockIdx.x + 1) * 128 > N;
+    const int nqt = (N + 31) / 32;
+
+    // staging plan (fixed per thread): source at tile 0, elements per tile, LDS slot
+    const unsigned short* src[NPRE];
+    int step[NPRE];
+    unsigned short* dst[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        int c = tid + k * NT;
+        if (RAGGED && k == NPRE - 1 && c >= NCHUNK) c = 0;
+        if (c < 128) {
+            src[k] = qt + (nb + (c >> 2)) * 32 + (c & 3) * 8;  step[k] = 32 * 32;
+            dst[k] = Qs + (c >> 2) * B_QLD + (c & 3) * 8;
+        } else {
+            const int c2 = c - 128;
+            const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
+            src[k] = dot_ + (nb + i) * CP + ch * 8;  step[k] = 32 * CP;
+            dst[k] = dOs + i * DLD + ch * 8;
+        }
+    }
+    const bool last_ok = !RAGGED || (tid + (NPRE - 1) * NT) < NCHUNK;
+
+    u32x4_t pre[NPRE];
+    float pre_s = 0.f;
+    auto load_tile = [&](int qtile) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
+        if (tid < 64) {
+            const int i = qtile * 32 + (tid & 31);
+            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            if (k < NPRE - 1 || last_ok) *reinterpret_cast<u32x4_t*>(dst[k]) = pre[k];
+        if (tid < 32) Ls[tid] = pre_s;
+        else if (tid < 64) Ds[tid - 32] = pre_s;
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int qtile = 0; qtile < nqt; ++qtile) {
+        const int i0 = qtile * 32;
+        if (qtile + 1 < nqt) load_tile(qtile + 1);
+
+        f32x16_t sacc, dpacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = Ls[acc_row(e, h)];
+            dpacc[e] = Ds[acc_row(e, h)];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
+            sacc = mfma_bf16(qa, kfB[s], sacc);
+        }
+#pragma unroll
+        for (int s = 0; s < 2 * CT; ++s) {
+            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
+            const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vls + (wave * 32 + r) * DLD + s * 16 + 8 * h);
+            dpacc = mfma_bf16(da, vb, dpacc);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
+        if (need_mask || i0 + 32 > N) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!(key_ok && (i0 + acc_row(e, h)) < N)) sacc[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpacc[e] *= sacc[e];   // dS
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            pf[s] = pack_frag(sacc, s);
+            dsf[s] = pack_frag(dpacc, s);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_tr_frag(dOs, DLD, s, ct * 32, lane), pf[s], dvacc[ct]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dkacc = mfma_bf16(read_tr_frag(Qs, B_QLD, s, 0, lane), dsf[s], dkacc);
+        __syncthreads();
+        if (qtile + 1 < nqt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    const int j = j0 + r;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+}
+
+// =====================================================================================================
 // backward, part 2: dQ^T  (query-parallel like the forward: a workgroup owns 128 queries and streams keys)
 //   S^T[j][i], dP^T[j][i] with the key on the accumulator rows and the query on the lane (lse/delta are lane
 //   constants), dS^T is the B operand of dQ^T[d][i] += K^T[d][j] dS^T[j][i]; dQ^T accumulates in registers --
@@ -917,14 +1087,21 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
                                 const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
                                 int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream) {
-    GD_CHECK_ARG(qt && kt && qn && kn && vt && dot_ && don && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
+    GD_CHECK_ARG(qt && kt && kn && vt && dot_ && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
     hipStream_t s = (hipStream_t)stream;
     // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
     // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
     static const int split_env = getenv("GD_PAM_DKV_SPLIT") ? atoi(getenv("GD_PAM_DKV_SPLIT")) : 0;
-    if (Cp == 192 && split_env) {   // alternative for Cp = 192: channel halves split over wave pairs (A/B switch)
+    static const int v3_env = getenv("GD_PAM_DKV_V3") ? atoi(getenv("GD_PAM_DKV_V3")) : 1;
+    GD_CHECK_ARG(v3_env || (qn && don), "gd_pam_flash_bwd: qn/don are required by the non-default dK/dV variants");
+    if (v3_env) {                   // transpose-read variant: 4 waves, two independent workgroups per CU
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
+                                                     (const unsigned short*)qt, (const unsigned short*)kt,
+                                                     (const unsigned short*)vt, (const unsigned short*)dot_, lse, delta,
+                                                     N, Npad, dkn, dv));
+    } else if (Cp == 192 && split_env) {   // alternative for Cp = 192: channel halves split over wave pairs (A/B switch)
         hipLaunchKernelGGL((pam_bwd_dkv_split_kernel<6>), dim3(Npad / 128, B), dim3(512), 0, s, (const unsigned short*)qt,
                            (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
                            (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);

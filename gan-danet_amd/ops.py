@@ -9,6 +9,7 @@ PAM runs the fused flash kernels, in "fp32" mode it runs the unfused reference-s
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -200,6 +201,10 @@ class DenseBlockFn(Function):
 # =====================================================================================================
 # dual attention: PAM || CAM into one 2C slab      generator.py:104-157
 # =====================================================================================================
+# the pre-v3 dK/dV kernels (GD_PAM_DKV_V3=0, kept for A/B runs) also need q and gamma*dOut channel-major
+_LEGACY_DKV = os.environ.get("GD_PAM_DKV_V3", "1") == "0"
+
+
 def _npad(n: int) -> int:
     return (n + 255) // 256 * 256
 
@@ -220,7 +225,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
     v = K.conv2d_fwd(x, wv, bv, 1, 0, prec).view(B, Cn, N)
     if fused:
         Np, Cp = _npad(N), _cp(Cn)
-        qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
+        qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np) if _LEGACY_DKV else None, t_shape=(Np, 32))
         kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
         vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp))
         del q, k, v
@@ -252,7 +257,8 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         Np, Cp = _npad(N), _cp(Cn)
         d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
         dgamma_p = K.dot(d_raw, None)
-        don, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, plain_shape=(Cp, Np), t_shape=(Np, Cp))
+        don, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, plain_shape=(Cp, Np) if _LEGACY_DKV else None,
+                                t_shape=(Np, Cp))
         dqn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)

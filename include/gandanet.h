@@ -215,7 +215,9 @@ int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N
 /* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad); vt (B,Npad,Cp);
  * dot (B,Npad,Cp) and don (B,Cp,Npad) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
  * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad).  Two launches: a key-parallel
- * kernel for dK/dV and a query-parallel kernel for dQ (no atomics: bitwise reproducible).  Npad % 256 == 0. */
+ * kernel for dK/dV and a query-parallel kernel for dQ (no atomics: bitwise reproducible).  Npad % 256 == 0.
+ * qn and don may be NULL: the default dK/dV kernel reads the transposed operands out of qt / dot with LDS
+ * transpose reads (they are only needed by the variants selected with GD_PAM_DKV_V3=0). */
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
                      const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
                      int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream);
