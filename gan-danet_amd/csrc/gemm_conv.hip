@@ -8,6 +8,8 @@
 // 16-byte staging writes and the 16-byte fragment reads are bank-conflict free.
 // Precision policies: BF16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) and FP32 (v_mfma_f32_32x32x2_f32,
 // bit-exact f32 fma chain) share every line except the fragment code.
+#include <stdlib.h>
+
 #include "common.h"
 #include "tile_mma.h"
 #include "../../include/gandanet.h"
@@ -205,6 +207,186 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
     }
 }
 
+// =====================================================================================================
+// 1x1 / stride 1 convolution (bf16): out[b][m][p] = sum_c A[b][m][c] * X~[b][c][p]
+// The activation operand is staged the way it lies in memory -- [channel][pixel], pixel-contiguous, float4
+// loads, 8-byte LDS writes -- and the MFMA B fragments (k = channel, n = pixel) are taken with
+// ds_read_b64_tr_b16, the LDS transpose read.  Rows are 128 pixels + 32 pad (320 B): the four channel rows of a
+// transpose-read block then start 16 banks apart, conflict free.
+// =====================================================================================================
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+constexpr int XLD = BN + 32;   // elements per staged channel row
+
+template <int BM>
+__global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
+    constexpr int LDA = BK + 8;
+    constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
+    constexpr int TM = gd::TileGeom<BM>::TM;
+    constexpr int TN = gd::TileGeom<BM>::TN;
+    constexpr int KPT_A = BM / 8;
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[BK * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int HW = d.Ho * d.Wo;
+
+    const int am = tid % BM, akg = tid / BM;
+    const bool a_row_ok = (m0 + am) < d.M;
+    const float* a_row = d.a + (long)b * d.a_bs + (long)(m0 + am) * d.a_sm;
+
+    // X loader: thread -> (channel row xr = tid>>3 .. +0, pixel quad xq = tid&7 .. +8*i): 32 rows x 32 quads
+    const int xq = tid & 31, xr0 = tid >> 5;          // 8 threads rows apart: rows xr0 + 8*i, quad xq
+    const float* x_img = d.x + (long)b * d.x_bs;
+    const int pq = n0 + xq * 4;                        // first pixel of this thread's quad
+    const bool q_full = pq + 3 < HW;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[KPT_A];
+    float4 rx[4];
+    const int T = (d.Ck + BK - 1) / BK;
+    auto load_tile = [&](int t) {
+        const int c0 = t * BK;
+#pragma unroll
+        for (int i = 0; i < KPT_A; ++i) {
+            const int c = c0 + akg * KPT_A + i;
+            ra[i] = (a_row_ok && c < d.Ck) ? a_row[(long)c * d.a_sc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + xr0 + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d.Ck) {
+                const float* p = x_img + (long)c * HW + pq;
+                if (q_full) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (pq + 0 < HW) v.x = p[0];
+                    if (pq + 1 < HW) v.y = p[1];
+                    if (pq + 2 < HW) v.z = p[2];
+                }
+                if (d.in_scale) {
+                    const float sc = d.in_scale[c], sh = d.in_shift[c];
+                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                    if (d.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (!q_full) {   // padding pixels stay zero
+                        if (pq + 0 >= HW) v.x = 0.f;
+                        if (pq + 1 >= HW) v.y = 0.f;
+                        if (pq + 2 >= HW) v.z = 0.f;
+                        v.w = 0.f;
+                    }
+                }
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+        unsigned short* ap = As + am * LDA + akg * KPT_A;
+        if constexpr (KPT_A >= 8) {
+#pragma unroll
+            for (int i = 0; i < KPT_A; i += 8) {
+                uint4 w;
+                w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
+                w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
+                w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
+                w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
+                *reinterpret_cast<uint4*>(ap + i) = w;
+            }
+        } else {
+            uint2 w;
+            w.x = gd_pack_bf2(ra[0], ra[1]);
+            w.y = gd_pack_bf2(ra[2], ra[3]);
+            *reinterpret_cast<uint2*>(ap) = w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 w;
+            w.x = gd_pack_bf2(rx[i].x, rx[i].y);
+            w.y = gd_pack_bf2(rx[i].z, rx[i].w);
+            *reinterpret_cast<uint2*>(Xs + (xr0 + 8 * i) * XLD + xq * 4) = w;
+        }
+    };
+    // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned short* p = Xs + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
+                        acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) load_tile(t + 1);
+        compute_tile();
+        __syncthreads();
+        if (t + 1 < T) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    const float alpha = d.alpha ? *d.alpha : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pn = n0 + wn * TN * 32 + j * 32 + r;
+            if (pn >= HW) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                if (m >= d.M) continue;
+                float v = acc[i][j][e] * alpha;
+                if (d.bias) v += d.bias[m];
+                if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HW + pn];
+                if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
+                float* yp = reinterpret_cast<float*>(d.y) + (long)b * d.y_bs + (long)m * HW + pn;
+                if (d.accumulate) v += *yp;
+                *yp = v;
+            }
+        }
+}
+
+static bool conv1x1_tr_eligible(const gd_conv_desc& d) {
+    const long HW = (long)d.Ho * d.Wo;
+    return d.ks == 1 && d.stride == 1 && d.pad == 0 && d.precision == GD_PREC_BF16 && d.out_layout == 0 && !d.out_bf16 &&
+           (d.Mstore == 0 || d.Mstore == d.M) && d.Hi == d.Ho && d.Wi == d.Wo && HW % 4 == 0 && d.x_bs % 4 == 0 &&
+           ((uintptr_t)d.x % 16) == 0;
+}
+
 template <int BM>
 int launch(const gd_conv_desc& d, hipStream_t s) {
     dim3 grid(gd_cdiv((long)d.Ho * d.Wo, BN), gd_cdiv(d.Mstore, BM), d.B);
@@ -240,6 +422,16 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
                      "gd_conv2d: transposed geometry mismatch");
     }
     hipStream_t s = (hipStream_t)stream;
+    static const int tr_env = getenv("GD_CONV1X1_TR") ? atoi(getenv("GD_CONV1X1_TR")) : 1;
+    if (tr_env && conv1x1_tr_eligible(d)) {
+        const int bm = d.M <= 32 ? 32 : (d.M <= 64 || (d.M % 128 != 0 && d.M % 128 <= 64)) ? 64 : 128;
+        dim3 grid(gd_cdiv((long)d.Ho * d.Wo, BN), gd_cdiv(d.M, bm), d.B);
+        if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_kernel<32>), grid, dim3(256), 0, s, d);
+        else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_kernel<64>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((conv1x1_tr_kernel<128>), grid, dim3(256), 0, s, d);
+        GD_LAUNCH_CHECK();
+        return 0;
+    }
     if (d.Mstore <= 32) return launch<32>(d, s);
     if (d.Mstore <= 64 || (d.Mstore % 128 != 0 && d.Mstore % 128 <= 64)) return launch<64>(d, s);
     return launch<128>(d, s);

@@ -28,7 +28,9 @@ __global__ void fill_zero_kernel(float* c, long c_bs, long ldc, int B, int M, in
     }
 }
 
-template <int BM, bool BF16>
+// VEC: plain (non-im2col) operands whose rows, leading dimensions and segments are 16-byte friendly are staged
+// with float4 loads (4 consecutive k per thread) and 8-byte LDS writes instead of scalar loads / 2-byte writes.
+template <int BM, bool BF16, bool VEC = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, int ktiles, int tiles_per_split,
                                                       int splits) {
     using P = gd::TilePol<BF16>;
@@ -89,6 +91,55 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float ra[RA], rb[RB];
+    // vector path: thread -> (row group r0v = tid>>3, k quad kq = tid&7); rows r0v + 32*i
+    constexpr int RAV = BM / 32, RBV = BN / 32;
+    float4 va[VEC ? RAV : 1], vb[VEC ? RBV : 1];
+    const int kq = tid & 7, r0v = tid >> 3;
+
+    auto load_tile_vec = [&](int t) {
+        const long k = (long)t * BK + kq * 4;          // klen % 32 == 0: a tile never straddles a segment
+        const bool k_ok = k < K;
+        const int s = k_ok ? (int)(k / d.klen) : 0;
+        const long kr = k_ok ? k - (long)s * d.klen : 0;
+        const float* ap = a_base + (long)s * d.a_ss + kr;
+        const float* bp = b_base + (long)s * d.b_ss + kr;
+#pragma unroll
+        for (int i = 0; i < RAV; ++i) {
+            const int m = m0 + r0v + 32 * i;
+            va[i] = (k_ok && m < d.M) ? *reinterpret_cast<const float4*>(ap + (long)m * d.lda) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RBV; ++i) {
+            const int n = n0 + r0v + 32 * i;
+            vb[i] = (k_ok && n < d.N) ? *reinterpret_cast<const float4*>(bp + (long)n * d.ldb) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile_vec = [&]() {
+#pragma unroll
+        for (int i = 0; i < RAV; ++i) {
+            if constexpr (BF16) {
+                uint2 w;
+                w.x = gd_pack_bf2(va[i].x, va[i].y);
+                w.y = gd_pack_bf2(va[i].z, va[i].w);
+                *reinterpret_cast<uint2*>(As + (r0v + 32 * i) * LD + kq * 4) = w;
+            } else {
+                float* p = reinterpret_cast<float*>(As) + (r0v + 32 * i) * LD + kq * 4;
+                p[0] = va[i].x; p[1] = va[i].y; p[2] = va[i].z; p[3] = va[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RBV; ++i) {
+            if constexpr (BF16) {
+                uint2 w;
+                w.x = gd_pack_bf2(vb[i].x, vb[i].y);
+                w.y = gd_pack_bf2(vb[i].z, vb[i].w);
+                *reinterpret_cast<uint2*>(Bs + (r0v + 32 * i) * LD + kq * 4) = w;
+            } else {
+                float* p = reinterpret_cast<float*>(Bs) + (r0v + 32 * i) * LD + kq * 4;
+                p[0] = vb[i].x; p[1] = vb[i].y; p[2] = vb[i].z; p[3] = vb[i].w;
+            }
+        }
+    };
 
     auto load_tile = [&](int t) {
         const long k = (long)t * BK + kk;
@@ -148,15 +199,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
     const int t_end = min(ktiles, t_begin + tiles_per_split);
     if (t_begin >= t_end) return;  // whole block exits together (uniform)
 
-    load_tile(t_begin);
-    store_tile();
+    if constexpr (VEC) {
+        load_tile_vec(t_begin);
+        store_tile_vec();
+    } else {
+        load_tile(t_begin);
+        store_tile();
+    }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
-        if (t + 1 < t_end) load_tile(t + 1);
+        if (t + 1 < t_end) {
+            if constexpr (VEC) load_tile_vec(t + 1);
+            else load_tile(t + 1);
+        }
         gd::tile_mma<BM, BF16>(As, Bs, wm, wn, r, h, acc);
         __syncthreads();
         if (t + 1 < t_end) {
-            store_tile();
+            if constexpr (VEC) store_tile_vec();
+            else store_tile();
             __syncthreads();
         }
     }
@@ -194,10 +254,18 @@ int launch(const gd_gemm_nt_desc& d, int ktiles, int splits, hipStream_t s) {
         hipLaunchKernelGGL(fill_zero_kernel, dim3(blocks), dim3(256), 0, s, d.c, d.c_bs, d.ldc, d.B, d.M, d.N);
     }
     dim3 grid(gd_cdiv(d.N, BN), gd_cdiv(d.M, BM), d.B * splits);
-    if (d.precision == GD_PREC_BF16)
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+    // float4 staging needs: plain operands, every row start / segment / batch offset a multiple of 4 floats from a
+    // 16-byte aligned base, and k tiles that never straddle a segment
+    const bool vec = !d.im2col && !d.in_scale && d.klen % BK == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+                     d.a_ss % 4 == 0 && d.b_ss % 4 == 0 && d.a_bs % 4 == 0 && d.b_bs % 4 == 0 &&
+                     ((uintptr_t)d.a % 16) == 0 && ((uintptr_t)d.bm % 16) == 0;
+    if (d.precision == GD_PREC_BF16) {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, true, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, true, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, false, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, false, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+    }
     GD_LAUNCH_CHECK();
     return 0;
 }

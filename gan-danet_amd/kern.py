@@ -206,6 +206,11 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
         L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift), int(in_relu), B,
                                        Cout, Cin, Hi, Wi, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
         return dw
+    if k == 1 and stride == 1 and pad == 0 and in_scale is None:
+        # 1x1: dW = dY X^T with both operands pixel-contiguous -> plain NT GEMM (float4-staged when aligned)
+        gemm_nt(B=1, M=Cout, N=Cin, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0, b_ss=xbs,
+                ldb=Hi * Wi, c=dw, c_bs=0, ldc=Cin, precision=precision)
+        return dw
     gemm_nt(B=1, M=Cout, N=Cin * k * k, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0,
             b_ss=xbs, ldb=0, c=dw, c_bs=0, ldc=Cin * k * k, precision=precision,
             im2col=(k, stride, pad, Hi, Wi, Ho, Wo), in_scale=in_scale, in_shift=in_shift, in_relu=in_relu)

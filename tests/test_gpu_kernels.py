@@ -312,3 +312,27 @@ def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
     assert_close(outs[True][1], dxr, BF16_TOL, "patch dgrad vs oracle", rell2)
     dwr = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, 3, 3), dy.cpu(), padding=1)
     assert_close(outs[True][2], dwr, BF16_TOL, "patch wgrad vs oracle", rell2)
+
+
+@pytest.mark.parametrize("shape", [(2, 184, 16, 16, 184), (1, 88, 8, 12, 44), (2, 520, 8, 8, 64), (1, 32, 5, 7, 24)])
+def test_conv1x1_transpose_read_kernel(gd, shape):
+    """1x1 convs (projections, transitions, channel_adjust): transpose-read kernel with and without the fused
+    BN-affine+ReLU prologue, forward / data gradient / weight gradient, against the oracle (bf16 operands).
+    The last shape (35 pixels) is not 16-byte friendly and must fall back to the generic kernel."""
+    ops, K = _ops()
+    from gan_danet_amd import _lib as L
+    B, Cin, H, W, Cout = shape
+    x = bf16_round(seeded((B, Cin, H, W), 71)).to(DEV)
+    w = bf16_round(seeded((Cout, Cin, 1, 1), 72, 1.0 / math.sqrt(Cin))).to(DEV)
+    bias = seeded((Cout,), 73, 0.1).to(DEV)
+    sc, sh = (seeded((Cin,), 74).abs() * 0.5 + 0.75).to(DEV), seeded((Cin,), 75, 0.2).to(DEV)
+    dy = bf16_round(seeded((B, Cout, H, W), 76)).to(DEV)
+    y = K.conv2d_fwd(x, w, bias, 1, 0, L.PREC_BF16)
+    yp = K.conv2d_fwd(x, w, bias, 1, 0, L.PREC_BF16, in_scale=sc, in_shift=sh, in_relu=True, act=ops.ACT_RELU)
+    dx = K.conv2d_dgrad(dy, w, (H, W), 1, 0, L.PREC_BF16)
+    dw = K.conv2d_wgrad(dy, x, 1, 1, 0, L.PREC_BF16)
+    assert_close(y, F.conv2d(x.cpu(), w.cpu(), bias.cpu()), BF16_TOL, "1x1 fwd")
+    xin = F.relu(x.cpu() * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+    assert_close(yp, F.relu(F.conv2d(xin, w.cpu(), bias.cpu())), BF16_TOL, "1x1 fwd prologue")
+    assert_close(dx, torch.nn.grad.conv2d_input((B, Cin, H, W), w.cpu(), dy.cpu()), BF16_TOL, "1x1 dgrad", rell2)
+    assert_close(dw, torch.nn.grad.conv2d_weight(x.cpu(), (Cout, Cin, 1, 1), dy.cpu()), BF16_TOL, "1x1 wgrad", rell2)
