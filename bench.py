@@ -163,12 +163,17 @@ def main():
 
     # ---- roofline of the dominant kernel from the HIP-event brackets recorded around its launches ----
     roof = None
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r01_pam_traffic.json")
+    if os.path.exists(tpath) and B == 32 and T == 256:   # PMC bytes measured offline at exactly this launch shape (C=184)
+        with open(tpath) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch", {})
     stats = kern.profile_summary()
     if stats:
         name, (n_launch, ms_avg, flops, nbytes) = max(stats.items(), key=lambda kv: kv[1][0] * kv[1][1])
         ach = flops / (ms_avg * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic.get(name),
                 "launches": n_launch, "avg_ms": round(ms_avg, 3),
                 "algorithmic_flop_per_launch": flops,
                 "all": {k: {"launches": v[0], "avg_ms": round(v[1], 3),
