@@ -391,6 +391,208 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
 }
 
 // =====================================================================================================
+// forward, software-pipelined LDS-DMA variant (GD_PAM_FWD_DMA=2; measured 5 % SLOWER than the plain DMA variant
+// on MI355X -- hipcc keeps the softmax VALU block after the MFMA block -- kept as the starting point for a
+// hand-scheduled version): the score tile and softmax of key tile t+1 are computed in the
+// same iteration as the P.V MFMAs of tile t (independent work in one basic block: the MFMA pipe runs the 24
+// P.V instructions while the VALU does max / exp / sum / pack of the next tile).  K tiles ride a 3-slot ring
+// (K(t+1) is needed while V(t) is), V tiles a 2-slot ring; one barrier per key tile.
+// =====================================================================================================
+template <int CT>
+__global__ __launch_bounds__(256, 2) void pam_fwd_pipe_kernel(const unsigned short* __restrict__ qt,
+                                                             const unsigned short* __restrict__ kt,
+                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ x,
+                                                             long x_bs, float* __restrict__ out, long out_bs,
+                                                             float* __restrict__ o_attn, float* __restrict__ lse) {
+    constexpr int CP = CT * 32;
+    constexpr int KCH = F_KT * D_KROWCH;            // 320 chunks = 5 pieces per K tile
+    constexpr int KPIECE = KCH / 64;
+    constexpr int VCH = CP * D_VROWCH;
+    constexpr int VPIECE = (VCH + 63) / 64;
+    constexpr int NPIECE = KPIECE + VPIECE;
+    constexpr int PPW = (NPIECE + 3) / 4;
+    constexpr int KSLOT = KCH * 8;                  // elements per K slot
+    constexpr int VSLOT = VPIECE * 64 * 8;          // elements per V slot
+    __shared__ __attribute__((aligned(16))) unsigned short ring[3 * KSLOT + 2 * VSLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const unsigned short* ktb = kt + (long)b * Npad * 32;
+    const unsigned short* vb = v + (long)b * CP * Npad;
+
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
+
+    const unsigned short* src[PPW];
+    bool live[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + 4 * i;
+        if (piece < KPIECE) {
+            const int c = piece * 64 + lane;
+            const int row = c / D_KROWCH, part = c - row * D_KROWCH;
+            src[i] = ktb + (long)row * 32 + (part < 4 ? part : 3) * 8;
+            live[i] = true;
+        } else {
+            const int c = (piece - KPIECE) * 64 + lane;
+            const int cc = c < VCH ? c : VCH - 1;
+            const int row = cc / D_VROWCH, part = cc - row * D_VROWCH;
+            src[i] = vb + (long)row * Npad + (part < 8 ? part : 7) * 8;
+            live[i] = piece < NPIECE && c < VCH;
+        }
+    }
+    // issue the K pieces of key tile tk (if >= 0) and the V pieces of key tile tv (if >= 0)
+    auto dma = [&](int tk, int tv) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < KPIECE) {
+                if (tk >= 0) {
+                    unsigned short* dst = ring + (tk % 3) * KSLOT + piece * 512;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(src[i] + (long)tk * (F_KT * 32)),
+                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            } else if (live[i] && tv >= 0) {
+                unsigned short* dst = ring + 3 * KSLOT + (tv & 1) * VSLOT + (piece - KPIECE) * 512;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)tv * F_KT),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16_t o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
+    float m = -1e30f, l = 0.f;
+    const int nkt = (N + F_KT - 1) / F_KT;
+
+    auto scores = [&](int t, f32x16_t (&sacc)[2]) {
+        const unsigned short* Ks = ring + (t % 3) * KSLOT;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
+                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
+            }
+        }
+        if ((t + 1) * F_KT > N) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
+        }
+    };
+    // online softmax of one score tile: returns the O rescale factor (1 when the max did not move), updates m, l,
+    // and leaves the packed bf16 probabilities in pf
+    auto softmax = [&](f32x16_t (&sacc)[2], bf16x8_t (&pf)[2][2]) -> float {
+        float mloc = sacc[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
+        const float m_new = fmaxf(m, mloc);
+        const float alpha = gd_exp2_fast(m - m_new);
+        m = m_new;
+        float lsum = 0.f;
+        const float neg_m = -m_new;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
+                sacc[sub][e] = p;
+                lsum += p;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l = l * alpha + lsum;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
+        return alpha;
+    };
+
+    // ---- prologue: K(0), V(0), K(1) in flight; scores + softmax of tile 0 ----
+    dma(0, 0);
+    if (nkt > 1) dma(1, -1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8_t pf_cur[2][2];
+    {
+        f32x16_t s0[2];
+        scores(0, s0);
+        (void)softmax(s0, pf_cur);   // O and l are still zero: the factor is irrelevant
+    }
+
+    for (int t = 0; t < nkt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K(t+1) / V(t) has landed
+        __syncthreads();                                    // ... everyone's has; K slot (t+2)%3 and V slot (t+1)&1 are free
+        dma(t + 2 < nkt ? t + 2 : -1, t + 1 < nkt ? t + 1 : -1);
+        const unsigned short* Vs = ring + 3 * KSLOT + (t & 1) * VSLOT;
+
+        float alpha = 1.f;
+        bf16x8_t pf_next[2][2];
+        const bool more = t + 1 < nkt;
+        f32x16_t sacc[2];
+        if (more) scores(t + 1, sacc);
+        // P(t).V(t) on the MFMA pipe; max / exp / sum / pack of tile t+1 on the VALU (independent of these MFMAs)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const unsigned short* vrow = Vs + (ct * 32 + r) * D_VLD;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    o[ct] = mfma_bf16(read_perm_frag(vrow, sub * 32 + s * 16, h), pf_cur[sub][s], o[ct]);
+        }
+        if (more) {
+            alpha = softmax(sacc, pf_next);
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pf_cur[sub][s] = pf_next[sub][s];
+        }
+    }
+
+    const int qi = q0 + r;
+    if (qi < N) {
+        const float inv_l = 1.f / l;
+        const float g = *gamma;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = ct * 32 + acc_row(e, h);
+                if (c < C) {
+                    const float val = o[ct][e] * inv_l;
+                    o_attn[((long)b * C + c) * N + qi] = val;
+                    out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
+                }
+            }
+        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
+    }
+}
+
+// =====================================================================================================
 // backward, part 1: dK^T and dV^T  (key-parallel; a workgroup owns NW*32 keys and sweeps the queries)
 // =====================================================================================================
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
@@ -1069,7 +1271,12 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
     dim3 grid(Npad / 128, B);
     static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 1;
-    if (dma_env) {
+    if (dma_env == 2) {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_pipe_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                     (const unsigned short*)qt, (const unsigned short*)kt,
+                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
+                                                     o_attn, lse));
+    } else if (dma_env) {
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
