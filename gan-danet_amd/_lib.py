@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("out_layout", C.c_int), ("out_bf16", C.c_int), ("ldo", C.c_int),
         ("alpha", c_fp), ("bias", c_fp), ("res", c_fp), ("res_bs", C.c_long),
         ("act", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int),
+        ("sub_oy", C.c_int), ("sub_ox", C.c_int), ("sub_step", C.c_int),
     ]
 
 
@@ -68,7 +69,7 @@ SIGNATURES = {
     "gd_bn_act_bwd": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p, _p, _p, _l, _i, _p, _p]),
     "gd_bicubic_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
     "gd_bicubic_bwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
-    "gd_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p]),
+    "gd_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "gd_bilinear_bwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "gd_maxpool2_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
     "gd_maxpool2_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),

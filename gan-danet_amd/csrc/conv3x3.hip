@@ -395,7 +395,8 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, lon
     a.tiles_y = (H + WTH - 1) / WTH;
     const long ntiles = (long)B * a.tiles_x * a.tiles_y;
     GD_CHECK_ARG(ntiles < (1L << 31), "gd_conv3x3_wgrad: too many tiles");
-    // m-tiles per workgroup: 2, 4 or 6 waves, whichever pads Cout least (ties -> the larger block)
+    // m-tiles per workgroup: 2, 4 or 6 waves, whichever pads Cout least (ties -> the larger block).  A 1-wave
+    // variant for Cout <= 32 was measured 2x SLOWER (64 threads stage the whole patch) and is not offered.
     int best_nw = 2;
     long best_pad = -1;
     for (int nw : {2, 4, 6}) {

@@ -54,10 +54,15 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
     // ---- B loader coordinates: thread -> (pixel bn, k half) -----------------------------------
     const int bn = tid & (BN - 1);
     const int bkh = tid >> 7;  // 0/1, each 16 wide
+    // pixels enumerate the output sub-lattice (step 1 = the whole image)
+    const int sstep = d.sub_step > 1 ? d.sub_step : 1;
+    const int Ws = (d.Wo - d.sub_ox + sstep - 1) / sstep, Hs = (d.Ho - d.sub_oy + sstep - 1) / sstep;
+    const int HsWs = Hs * Ws;
     const int p = n0 + bn;
-    const bool p_ok = p < HoWo;
-    const int oy = p_ok ? p / d.Wo : 0;
-    const int ox = p_ok ? p - oy * d.Wo : 0;
+    const bool p_ok = p < HsWs;
+    const int pa = p_ok ? p / Ws : 0;
+    const int oy = d.sub_oy + pa * sstep;
+    const int ox = d.sub_ox + (p_ok ? p - pa * Ws : 0) * sstep;
     const float* x_img = d.x + (long)b * d.x_bs;
 
     f32x16_t acc[TM][TN];
@@ -161,17 +166,33 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
 
     auto compute_tile = [&]() { gd::tile_mma<BM, BF16>(As, Bs, wm, wn, r, h, acc); };
 
-    load_tile(0);
-    store_tile();
+    // tiles whose tap cannot reach this output parity class are skipped (workgroup-uniform; strided data gradient)
+    auto tile_live = [&](int t) -> bool {
+        if (!d.transposed || sstep == 1) return true;
+        const int tap = t / ktiles_per_tap;
+        const int kh = tap / d.ks, kw = tap - kh * d.ks;
+        return ((d.sub_oy + d.pad - kh) % d.stride == 0) && ((d.sub_ox + d.pad - kw) % d.stride == 0);
+    };
+    auto next_live = [&](int t) -> int {
+        while (t < T && !tile_live(t)) ++t;
+        return t;
+    };
+    int t = next_live(0);
+    if (t < T) {
+        load_tile(t);
+        store_tile();
+    }
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) load_tile(t + 1);  // global loads in flight under the MFMAs
+    while (t < T) {
+        const int tn = next_live(t + 1);
+        if (tn < T) load_tile(tn);  // global loads in flight under the MFMAs
         compute_tile();
         __syncthreads();
-        if (t + 1 < T) {
+        if (tn < T) {
             store_tile();
             __syncthreads();
         }
+        t = tn;
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
@@ -180,8 +201,10 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int pn = n0 + wn * TN * 32 + j * 32 + r;
-            if (pn >= HoWo) continue;
+            const int ps = n0 + wn * TN * 32 + j * 32 + r;
+            if (ps >= HsWs) continue;
+            const int qa = ps / Ws;
+            const int pn = (d.sub_oy + qa * sstep) * d.Wo + d.sub_ox + (ps - qa * Ws) * sstep;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
@@ -389,7 +412,10 @@ static bool conv1x1_tr_eligible(const gd_conv_desc& d) {
 
 template <int BM>
 int launch(const gd_conv_desc& d, hipStream_t s) {
-    dim3 grid(gd_cdiv((long)d.Ho * d.Wo, BN), gd_cdiv(d.Mstore, BM), d.B);
+    const int sstep = d.sub_step > 1 ? d.sub_step : 1;
+    const long hs = (d.Ho - d.sub_oy + sstep - 1) / sstep, ws = (d.Wo - d.sub_ox + sstep - 1) / sstep;
+    if (hs <= 0 || ws <= 0) return 0;
+    dim3 grid(gd_cdiv(hs * ws, BN), gd_cdiv(d.Mstore, BM), d.B);
     if (d.precision == GD_PREC_BF16)
         hipLaunchKernelGGL((conv_nn_kernel<BM, true>), grid, dim3(256), 0, s, d);
     else
@@ -412,6 +438,8 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
     GD_CHECK_ARG(d.out_layout == 0 || (d.out_layout == 1 && d.ldo >= d.Mstore), "gd_conv2d: bad output layout");
     GD_CHECK_ARG(!(d.out_bf16 && d.accumulate), "gd_conv2d: accumulate needs an fp32 output");
     GD_CHECK_ARG((long)d.Ho * d.Wo < (1L << 31) && d.B <= 65535, "gd_conv2d: image too large for one launch");
+    GD_CHECK_ARG(d.sub_step >= 0 && d.sub_oy >= 0 && d.sub_ox >= 0 && (d.sub_step > 1 || (d.sub_oy == 0 && d.sub_ox == 0)),
+                 "gd_conv2d: bad output sub-lattice");
     if (!d.transposed) {
         // forward gather: the output size must be what this geometry produces
         GD_CHECK_ARG((d.Hi + 2 * d.pad - d.ks) / d.stride + 1 == d.Ho && (d.Wi + 2 * d.pad - d.ks) / d.stride + 1 == d.Wo,
@@ -432,7 +460,21 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
         GD_LAUNCH_CHECK();
         return 0;
     }
-    if (d.Mstore <= 32) return launch<32>(d, s);
-    if (d.Mstore <= 64 || (d.Mstore % 128 != 0 && d.Mstore % 128 <= 64)) return launch<64>(d, s);
-    return launch<128>(d, s);
+    auto run = [&](const gd_conv_desc& dd) -> int {
+        if (dd.Mstore <= 32) return launch<32>(dd, s);
+        if (dd.Mstore <= 64 || (dd.Mstore % 128 != 0 && dd.Mstore % 128 <= 64)) return launch<64>(dd, s);
+        return launch<128>(dd, s);
+    };
+    if (d.transposed && d.stride > 1 && d.sub_step <= 1) {
+        // data gradient of a strided conv: one launch per output parity class, each with its reachable taps only
+        for (int py = 0; py < d.stride; ++py)
+            for (int px = 0; px < d.stride; ++px) {
+                gd_conv_desc dd = d;
+                dd.sub_oy = py; dd.sub_ox = px; dd.sub_step = d.stride;
+                const int rc = run(dd);
+                if (rc) return rc;
+            }
+        return 0;
+    }
+    return run(d);
 }

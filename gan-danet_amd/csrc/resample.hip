@@ -149,9 +149,92 @@ __global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const float* __r
     dx[bc * (long)Hi * Wi + (long)iy * Wi + ix] = acc;
 }
 
+// Backward of the exact x2 bicubic upsample (the only bicubic on the training path, generator.py:221,225).
+// For scale 2 the fractional offsets are only 0.25 / 0.75, so an interior input pixel i receives from the eight
+// output rows 2i-3 .. 2i+4 with eight FIXED weights (even rows 2(i+2-k) carry cubic_w(0.75)[k], odd rows
+// 2(i+1-k)+1 carry cubic_w(0.25)[k]).  Border pixels (index 0 or n-1, where clamped taps pile up) take the
+// general window routine.
+__device__ __forceinline__ void up2_weights(int i, int n_in, int n_out, float rs, int& lo, float (&w)[WMAX]) {
+    if (i >= 1 && i <= n_in - 2) {
+        float w75[4], w25[4];
+        cubic_w(0.75f, w75);
+        cubic_w(0.25f, w25);
+        lo = 2 * i - 3;
+        // offsets 0..7 <-> rows 2i-3 .. 2i+4 : odd rows (v_k, k = 3..0) interleaved with even rows (w_k, k = 3..0)
+        const float t[8] = {w25[3], w75[3], w25[2], w75[2], w25[1], w75[1], w25[0], w75[0]};
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k) {
+            const int o = lo + k;
+            w[k] = (k < 8 && o >= 0 && o < n_out) ? t[k < 8 ? k : 0] : 0.f;
+        }
+    } else {
+        int hi;
+        cubic_window(i, rs, n_in, n_out, lo, hi);
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k) {
+            const int o = lo + k;
+            float ww = 0.f;
+            if (o <= hi) {
+                int idx[4];
+                float cw[4];
+                cubic_taps(o, rs, n_in, idx, cw);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ww += (idx[q] == i) ? cw[q] : 0.f;
+            }
+            w[k] = ww;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bicubic_up2_bwd_kernel(const float* __restrict__ dy, int Hi, int Wi,
+                                                             float* __restrict__ dx) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int ix = blockIdx.x * 256 + threadIdx.x;
+    const int iy = blockIdx.y;
+    const long bc = blockIdx.z;
+    if (ix >= Wi) return;
+    const float* g = dy + bc * (long)Ho * Wo;
+    float acc = 0.f;
+    if (iy >= 2 && iy <= Hi - 3 && ix >= 2 && ix <= Wi - 3) {
+        // interior: all 8 x 8 contributing outputs exist; fixed weights, fully unrolled, two float4 loads per row
+        float w75[4], w25[4];
+        cubic_w(0.75f, w75);
+        cubic_w(0.25f, w25);
+        const float t[8] = {w25[3], w75[3], w25[2], w75[2], w25[1], w75[1], w25[0], w75[0]};
+        const float* p = g + (long)(2 * iy - 3) * Wo + (2 * ix - 3);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const float* row = p + (long)a * Wo;
+            float rsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rsum = fmaf(row[k], t[k], rsum);
+            acc = fmaf(rsum, t[a], acc);
+        }
+    } else {
+        int xlo, ylo;
+        float wx[WMAX], wy[WMAX];
+        up2_weights(ix, Wi, Wo, 0.5f, xlo, wx);
+        up2_weights(iy, Hi, Ho, 0.5f, ylo, wy);
+#pragma unroll
+        for (int a = 0; a < WMAX; ++a) {
+            const int oy = ylo + a;
+            if (wy[a] == 0.f || oy < 0 || oy >= Ho) continue;
+            const float* row = g + (long)oy * Wo;
+            float rsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < WMAX; ++k) {
+                const int ox = xlo + k;
+                if (wx[k] != 0.f) rsum = fmaf(row[ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox)], wx[k], rsum);
+            }
+            acc = fmaf(rsum, wy[a], acc);
+        }
+    }
+    dx[bc * (long)Hi * Wi + (long)iy * Wi + ix] = acc;
+}
+
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int Hi, int Wi,
                                                           float* __restrict__ y, int Ho, int Wo, float rsh, float rsw,
-                                                          int accumulate) {
+                                                          int accumulate, const float* __restrict__ res) {
     const int ox = blockIdx.x * 256 + threadIdx.x;
     const int oy = blockIdx.y;
     const long bc = blockIdx.z;
@@ -166,9 +249,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
     const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
     float v = top * (1.f - ly) + bot * ly;
-    float* q = y + bc * (long)Ho * Wo + (long)oy * Wo + ox;
-    if (accumulate) v += *q;
-    *q = v;
+    const long oidx = bc * (long)Ho * Wo + (long)oy * Wo + ox;
+    if (res) v += res[oidx];          // y = res + bilinear(x) in one pass (skip addition, generator.py:245)
+    else if (accumulate) v += y[oidx];
+    y[oidx] = v;
 }
 
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int Hi, int Wi,
@@ -242,6 +326,13 @@ extern "C" int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx
                               void* stream) {
     GD_CHECK_ARG(dy && dx, "gd_bicubic_bwd: null pointer");
     if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bicubic_bwd: bad sizes")) return -1;
+    if (Ho == 2 * Hi && Wo == 2 * Wi && rsh == 0.5f && rsw == 0.5f && Hi >= 2 && Wi >= 2) {   // exact x2: fixed weights
+        GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bicubic_up2_bwd_kernel, dim3(gd_cdiv(Wi, 256), Hi, nz_), dim3(256), 0,
+                                                (hipStream_t)stream, dy + z0_ * (long)Ho * Wo, Hi, Wi,
+                                                dx + z0_ * (long)Hi * Wi);)
+        GD_LAUNCH_CHECK();
+        return 0;
+    }
     GD_CHECK_ARG(4.f / rsw + 5.f <= (float)WMAX, "gd_bicubic_bwd: scale factor too large for the gather window");
     GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL((resize_bwd_gather_kernel<true>), dim3(gd_cdiv(Wi, 256), Hi, nz_), dim3(256),
                                             0, (hipStream_t)stream, dy + z0_ * (long)Ho * Wo, Hi, Wi,
@@ -251,13 +342,14 @@ extern "C" int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx
 }
 
 extern "C" int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate,
-                               void* stream) {
+                               const float* res, void* stream) {
     GD_CHECK_ARG(x && y, "gd_bilinear_fwd: null pointer");
     if (check_plane(BC, Hi, Wi, Ho, Wo, "gd_bilinear_fwd: bad sizes")) return -1;
     const float rsh = (float)Hi / (float)Ho, rsw = (float)Wi / (float)Wo;
     GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(gd_cdiv(Wo, 256), Ho, nz_), dim3(256), 0,
                                             (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
-                                            y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw, accumulate);)
+                                            y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw, accumulate,
+                                            res ? res + z0_ * (long)Ho * Wo : (const float*)nullptr);)
     GD_LAUNCH_CHECK();
     return 0;
 }

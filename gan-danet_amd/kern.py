@@ -309,14 +309,20 @@ def bicubic_bwd(dy: Tensor, Hi: int, Wi: int, rsh: float, rsw: float) -> Tensor:
     return dx
 
 
-def bilinear_fwd(x: Tensor, Ho: int, Wo: int, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+def bilinear_fwd(x: Tensor, Ho: int, Wo: int, out: Optional[Tensor] = None, accumulate: bool = False,
+                 res: Optional[Tensor] = None) -> Tensor:
+    """out = bilinear(x) [+ out if accumulate] [or res + bilinear(x) when ``res`` is given]"""
     _dense(x, "bilinear input")
     B, Cn, Hi, Wi = x.shape
     if out is None:
         out = torch.empty(B, Cn, Ho, Wo, device=x.device, dtype=torch.float32)
         accumulate = False
     _dense(out, "bilinear out")
-    L.check(lib().gd_bilinear_fwd(_ptr(x), B * Cn, Hi, Wi, _ptr(out), Ho, Wo, int(accumulate), _stream()),
+    if res is not None:
+        _dense(res, "bilinear residual")
+        if res.shape != out.shape:
+            raise L.GandanetError("bilinear_fwd: residual shape mismatch")
+    L.check(lib().gd_bilinear_fwd(_ptr(x), B * Cn, Hi, Wi, _ptr(out), Ho, Wo, int(accumulate), _ptr(res), _stream()),
             "gd_bilinear_fwd")
     return out
 

@@ -490,9 +490,7 @@ class SkipFuseFn(Function):
             if f.shape[2:] != fs[0].shape[2:]:
                 raise L.GandanetError("SkipFuseFn: all skip features must share one resolution")
             K.conv2d_fwd(f, w, None, 1, 0, prec, out=s, accumulate=True)
-        out = torch.empty_like(x)
-        K.copy_slab(x, out)
-        K.bilinear_fwd(s, Ho, Wo, out=out, accumulate=True)
+        out = K.bilinear_fwd(s, Ho, Wo, res=x)     # x + up(s): one pass over the 4H x 4W tensor
         ctx.save_for_backward(*ws, *fs)
         ctx.cfg = (prec, n)
         return out

@@ -19,6 +19,7 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
+from . import kern as K
 from . import ops
 from .optim import AdamW
 from .parallel import GradReducer, world_size
@@ -35,7 +36,8 @@ class StepOutput:
 class GanTrainer:
     def __init__(self, G: nn.Module, D: nn.Module, perceptual: Optional[nn.Module] = None, lr_g: float = 2e-4,
                  lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
-                 compute_ssim: bool = True, tv_global_batch_semantics: bool = False) -> None:
+                 compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
+                 batch_real_fake: bool = True) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
         ws = world_size()
         self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
@@ -47,6 +49,7 @@ class GanTrainer:
         # per-shard oracle computes it); set tv_global_batch_semantics to scale it back by 1/world.
         self.tv_weight = tv_weight / ws if tv_global_batch_semantics else tv_weight
         self.compute_ssim = compute_ssim
+        self.batch_real_fake = batch_real_fake
 
     def step(self, x: torch.Tensor, target: torch.Tensor, loss_weight: float) -> StepOutput:
         G, D = self.G, self.D
@@ -54,8 +57,18 @@ class GanTrainer:
 
         # ---- discriminator update (L246-256) ----
         self.opt_d.zero_grad(set_to_none=True)
-        real = D(target)
-        fake = D(hr.detach())
+        if self.batch_real_fake and target.shape == hr.shape:
+            # D has no BatchNorm, so D(cat[real, fake]) == (D(real), D(fake)) exactly; one pass streams fc1's
+            # weights once per forward / data-gradient / weight-gradient instead of twice
+            nb = target.shape[0]
+            both = torch.empty((2 * nb,) + tuple(target.shape[1:]), device=target.device, dtype=torch.float32)
+            K.copy_slab(target if target.is_contiguous() else target.contiguous(), both[:nb])
+            K.copy_slab(hr.detach(), both[nb:])
+            logits = D(both)
+            real, fake = logits[:nb], logits[nb:]
+        else:
+            real = D(target)
+            fake = D(hr.detach())
         loss_d = ops.weighted_sum([0.5, 0.5], [ops.bce_with_logits(real, 1.0), ops.bce_with_logits(fake, 0.0)])
         loss_d.backward()
         self.red_d.reduce()

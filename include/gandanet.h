@@ -70,6 +70,11 @@ typedef struct gd_conv_desc {
     const float* alpha; const float* bias; const float* res; long res_bs;
     int act; int accumulate;
     int precision;
+    /* output sub-lattice (0,0,0 or step 1 = every pixel): only outputs (sub_oy + a*sub_step, sub_ox + b*sub_step)
+       are computed.  gd_conv2d uses it internally to split the data gradient of a STRIDED convolution into
+       stride^2 launches, one per output parity class, each visiting only the taps that can reach that class
+       (a stride-2 3x3 gradient then does 9/4 instead of 9 tap-GEMMs per pixel). */
+    int sub_oy, sub_ox, sub_step;
 } gd_conv_desc;
 int gd_conv2d(const gd_conv_desc* d, void* stream);
 
@@ -153,8 +158,10 @@ int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int
                    float rscale_w, void* stream);
 int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, float rscale_h,
                    float rscale_w, void* stream); /* dx (BC,Hi,Wi) overwritten */
-/* y (+)= bilinear(x): accumulate=1 fuses the skip addition of generator.py:245 */
-int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate, void* stream);
+/* y = bilinear(x) (+ y if accumulate) ; or, when res != NULL, y = res + bilinear(x) in one pass: the skip
+ * addition of generator.py:245 without a separate copy */
+int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate,
+                    const float* res, void* stream);
 int gd_bilinear_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, void* stream);
 int gd_maxpool2_fwd(const float* x, int BC, int Hi, int Wi, float* y, void* stream);
 int gd_maxpool2_bwd(const float* x, const float* dy, int BC, int Hi, int Wi, float* dx, void* stream);
