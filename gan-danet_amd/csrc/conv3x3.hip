@@ -96,32 +96,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * CK;
         load_w(chunk, 0);
-        // ---- stage the input patch of this chunk: [pixel][channel], two channels per thread per pass ----
-        // element id = cpair * NPIX + pix  -> lanes walk pixels (coalesced rows of 34), 16 channel pairs
-        for (int id = tid; id < (CK / 2) * NPIX; id += 256) {
-            const int cp = id / NPIX, pix = id - cp * NPIX;
+        // ---- stage the input patch of this chunk: [pixel][channel] ----
+        // work item = (patch pixel, channel half): bounds, address and LDS slot are computed once per item, then 8
+        // channel pairs are walked with a constant stride (lanes = consecutive pixels: coalesced 34-pixel rows)
+        for (int w = tid; w < 2 * NPIX; w += 256) {
+            const int half = w >= NPIX ? 1 : 0;
+            const int pix = w - half * NPIX;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            const int c = c0 + 2 * cp;
-            float v0 = 0.f, v1 = 0.f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const float* p = ximg + (long)c * HW + (long)iy * W + ix;
-                if (c < d.Ck) {
-                    v0 = p[0];
+            const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cb = c0 + half * 16;
+            const float* p = ximg + (long)cb * HW + (long)iy * W + ix;
+            unsigned int* dst = reinterpret_cast<unsigned int*>(patch + pix * LD + half * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cb + 2 * j;
+                float v0 = 0.f, v1 = 0.f;
+                if (inside) {
+                    if (c < d.Ck) v0 = p[(long)(2 * j) * HW];
+                    if (c + 1 < d.Ck) v1 = p[(long)(2 * j + 1) * HW];
                     if (d.in_scale) {
-                        v0 = fmaf(v0, d.in_scale[c], d.in_shift[c]);
-                        if (d.in_relu) v0 = fmaxf(v0, 0.f);
+                        if (c < d.Ck) {
+                            v0 = fmaf(v0, d.in_scale[c], d.in_shift[c]);
+                            if (d.in_relu) v0 = fmaxf(v0, 0.f);
+                        }
+                        if (c + 1 < d.Ck) {
+                            v1 = fmaf(v1, d.in_scale[c + 1], d.in_shift[c + 1]);
+                            if (d.in_relu) v1 = fmaxf(v1, 0.f);
+                        }
                     }
                 }
-                if (c + 1 < d.Ck) {
-                    v1 = p[HW];
-                    if (d.in_scale) {
-                        v1 = fmaf(v1, d.in_scale[c + 1], d.in_shift[c + 1]);
-                        if (d.in_relu) v1 = fmaxf(v1, 0.f);
-                    }
-                }
+                dst[j] = gd_pack_bf2(v0, v1);
             }
-            *reinterpret_cast<unsigned int*>(patch + pix * LD + 2 * cp) = gd_pack_bf2(v0, v1);
         }
         for (int ky = 0; ky < 3; ++ky) {
             store_w();
@@ -314,31 +320,36 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             w.y = gd_pack_bf2(f.z, f.w);
             *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
         }
-        // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU), two channels per thread per pass ----
-        for (int id = tid; id < (CK / 2) * WNPIX; id += NT) {
-            const int cp = id / WNPIX, pix = id - cp * WNPIX;
+        // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU): item = (patch pixel, channel half) ----
+        for (int w = tid; w < 2 * WNPIX; w += NT) {
+            const int half = w >= WNPIX ? 1 : 0;
+            const int pix = w - half * WNPIX;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            const int c = c0 + 2 * cp;
-            float v0 = 0.f, v1 = 0.f;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                const float* p = xb + (long)c * HW + (long)iy * a.W + ix;
-                if (c < a.Ck) {
-                    v0 = p[0];
+            const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int cb = c0 + half * 16;
+            const float* p = xb + (long)cb * HW + (long)iy * a.W + ix;
+            unsigned int* dst = reinterpret_cast<unsigned int*>(patch + pix * LD + half * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cb + 2 * j;
+                float v0 = 0.f, v1 = 0.f;
+                if (inside) {
+                    if (c < a.Ck) v0 = p[(long)(2 * j) * HW];
+                    if (c + 1 < a.Ck) v1 = p[(long)(2 * j + 1) * HW];
                     if (a.in_scale) {
-                        v0 = fmaf(v0, a.in_scale[c], a.in_shift[c]);
-                        if (a.in_relu) v0 = fmaxf(v0, 0.f);
+                        if (c < a.Ck) {
+                            v0 = fmaf(v0, a.in_scale[c], a.in_shift[c]);
+                            if (a.in_relu) v0 = fmaxf(v0, 0.f);
+                        }
+                        if (c + 1 < a.Ck) {
+                            v1 = fmaf(v1, a.in_scale[c + 1], a.in_shift[c + 1]);
+                            if (a.in_relu) v1 = fmaxf(v1, 0.f);
+                        }
                     }
                 }
-                if (c + 1 < a.Ck) {
-                    v1 = p[HW];
-                    if (a.in_scale) {
-                        v1 = fmaf(v1, a.in_scale[c + 1], a.in_shift[c + 1]);
-                        if (a.in_relu) v1 = fmaxf(v1, 0.f);
-                    }
-                }
+                dst[j] = gd_pack_bf2(v0, v1);
             }
-            *reinterpret_cast<unsigned int*>(patch + pix * LD + 2 * cp) = gd_pack_bf2(v0, v1);
         }
         __syncthreads();
 
