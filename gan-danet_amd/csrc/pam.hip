@@ -59,7 +59,7 @@ __device__ __forceinline__ bf16x8_t read_perm_frag(const unsigned short* row, in
 // =====================================================================================================
 constexpr int F_KT = 64;    // keys per tile
 constexpr int F_KLD = 40;   // K row: 32 d + 8 pad (80 B) -> conflict-free 16-B fragment reads
-constexpr int F_VLD = 68;   // V row: 64 keys + 4 pad (136 B) -> conflict-free 8-B fragment reads
+constexpr int F_VLD = 72;   // V row: 64 keys + 8 pad (144 B) -> conflict-free 16-B fragment reads (keys perm16-ordered)
 
 template <int CT>
 __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* __restrict__ qt,
@@ -115,9 +115,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
         for (int i = 0; i < CT; ++i) {
             const int idx = tid + i * 256;
             const int c = idx >> 3, qd = idx & 7;
-            u32x2_t* dst = reinterpret_cast<u32x2_t*>(Vs + c * F_VLD + qd * 8);  // 136-B rows: 8-B aligned only
-            dst[0] = u32x2_t{vreg[i].x, vreg[i].y};
-            dst[1] = u32x2_t{vreg[i].z, vreg[i].w};
+            *reinterpret_cast<u32x4_t*>(Vs + c * F_VLD + qd * 8) = vreg[i];   // 144-B rows: 16-byte aligned
         }
     };
 
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8_t vf = read_perm_frag(vrow, sub * 32 + s * 16, h);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h);
                     o[ct] = mfma_bf16(vf, pf[sub][s], o[ct]);
                 }
         }
@@ -367,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    o[ct] = mfma_bf16(read_perm_frag(vrow, sub * 32 + s * 16, h), pf[sub][s], o[ct]);
+                    o[ct] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h), pf[sub][s], o[ct]);
         }
     }
 
@@ -556,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_pipe_kernel(const unsigned sho
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    o[ct] = mfma_bf16(read_perm_frag(vrow, sub * 32 + s * 16, h), pf_cur[sub][s], o[ct]);
+                    o[ct] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h), pf_cur[sub][s], o[ct]);
         }
         if (more) {
             alpha = softmax(sacc, pf_next);
@@ -1143,6 +1141,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
 //   no atomics, deterministic, and it is stored channel-major (the layout the projection gradients read).
 // =====================================================================================================
 constexpr int Q_KT = 64;
+constexpr int Q_KNLD = 68;   // K^T rows [d][64 keys] + 4 pad (136 B): conflict-free 8-byte permuted reads
 
 template <int CT>
 __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
@@ -1152,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
     constexpr int CP = CT * 32;
     constexpr int VLD = CP + 8;   // V tile rows [key][CP c]: 16-B reads conflict free
     __shared__ __attribute__((aligned(16))) unsigned short Ks[Q_KT * F_KLD];    // K rows [key][32 d]
-    __shared__ __attribute__((aligned(16))) unsigned short KNs[32 * F_VLD];     // K^T rows [d][64 keys]
+    __shared__ __attribute__((aligned(16))) unsigned short KNs[32 * Q_KNLD];     // K^T rows [d][64 keys]
     __shared__ __attribute__((aligned(16))) unsigned short VTs[Q_KT * VLD];     // V rows [key][CP c]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1190,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
     };
     auto store_tile = [&]() {
         *reinterpret_cast<u32x4_t*>(Ks + (tid >> 2) * F_KLD + (tid & 3) * 8) = kreg;
-        u32x2_t* kd = reinterpret_cast<u32x2_t*>(KNs + (tid >> 3) * F_VLD + (tid & 7) * 8);
+        u32x2_t* kd = reinterpret_cast<u32x2_t*>(KNs + (tid >> 3) * Q_KNLD + (tid & 7) * 8);
         kd[0] = u32x2_t{knreg.x, knreg.y};
         kd[1] = u32x2_t{knreg.z, knreg.w};
 #pragma unroll
@@ -1235,7 +1234,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
                 for (int e = 0; e < 16; ++e)
                     if ((t * Q_KT + sub * 32 + acc_row(e, h)) >= N) dpacc[e] = 0.f;
             }
-            const unsigned short* krow = KNs + r * F_VLD;
+            const unsigned short* krow = KNs + r * Q_KNLD;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 dq = mfma_bf16(read_perm_frag(krow, sub * 32 + s * 16, h), pack_frag(dpacc, s), dq);

@@ -497,7 +497,8 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta
 
 
 # ---- PAM helpers ------------------------------------------------------------------------------------
-def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, plain_shape=None, t_shape=None):
+def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, plain_shape=None, t_shape=None,
+              perm16: bool = False):
     """s: (B, R, Cc)-like fp32 block (per-image dense).  Returns (plain, transposed) bf16 tensors (or None)."""
     sbs = _bview(s, "pack input")
     B = s.shape[0]
@@ -509,8 +510,8 @@ def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, pla
     if t_shape is not None:
         ccp, ldt = t_shape
         tr = torch.empty(B, ccp, ldt, device=s.device, dtype=torch.bfloat16)
-    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), _ptr(plain), rp, ldp, _ptr(tr), ccp, ldt, _stream()),
-            "gd_pack_bf16")
+    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), _ptr(plain), rp, ldp, _ptr(tr), ccp, ldt,
+                               int(perm16), _stream()), "gd_pack_bf16")
     return plain, tr
 
 

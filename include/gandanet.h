@@ -212,7 +212,7 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
 /* ------------------------------------------------------------------------------------------
  * PAM, fused (flash) form in bf16 with fp32 softmax statistics (generator.py:115-122).
  *   qt, kt : (B, Npad, 32) bf16, d zero-padded to 32      (pixel-major)
- *   v      : (B, Cp, Npad) bf16, Cp = C rounded up to 32   (channel-major)
+ *   v      : (B, Cp, Npad) bf16, Cp = C rounded up to 32   (channel-major, keys perm16-ordered: gd_pack_bf16)
  *   x, out : (B, C, N) fp32 with batch strides; out = gamma * attn + x
  *   o_attn : (B, C, N) fp32 un-scaled attention output (kept for backward), lse : (B, N) fp32
  * ---------------------------------------------------------------------------------------- */
@@ -233,9 +233,11 @@ int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int
                 float* d_raw, float* delta, void* stream);
 /* fp32 (B, R, Cc) planes (batch stride s_bs), optionally times a device scalar -> bf16:
  *   plain      (B, Rp_plain, ld_plain)  zero padded copy          (NULL to skip)
- *   transposed (B, Ccp_t, ld_t)         zero padded transpose     (NULL to skip) */
+ *   transposed (B, Ccp_t, ld_t)         zero padded transpose     (NULL to skip)
+ * perm16 != 0: inside every 16 columns of `plain` the order is [0-3, 8-11, 4-7, 12-15] (the order an MFMA lane
+ * half consumes an accumulator-row-ordered k-step: gd_pam_flash_fwd expects its V operand packed this way). */
 int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, void* plain, int Rp_plain,
-                 int ld_plain, void* transposed, int Ccp_t, int ld_t, void* stream);
+                 int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, void* stream);
 
 #ifdef __cplusplus
 }

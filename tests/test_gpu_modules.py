@@ -93,7 +93,7 @@ def test_pam_flash_properties_large(gd):
     def run(qq, kk, vv):
         _, qt = K.pack_bf16(qq, r, N, t_shape=(Np, 32))
         _, kt = K.pack_bf16(kk, r, N, t_shape=(Np, 32))
-        vn, _ = K.pack_bf16(vv, C, N, plain_shape=(Cp, Np))
+        vn, _ = K.pack_bf16(vv, C, N, plain_shape=(Cp, Np), perm16=True)
         out = torch.empty(B, C, N, device=DEV)
         o = torch.empty(B, C, N, device=DEV)
         lse = torch.empty(B, N, device=DEV)
