@@ -389,208 +389,6 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
 }
 
 // =====================================================================================================
-// forward, software-pipelined LDS-DMA variant (GD_PAM_FWD_DMA=2; measured 5 % SLOWER than the plain DMA variant
-// on MI355X -- hipcc keeps the softmax VALU block after the MFMA block -- kept as the starting point for a
-// hand-scheduled version): the score tile and softmax of key tile t+1 are computed in the
-// same iteration as the P.V MFMAs of tile t (independent work in one basic block: the MFMA pipe runs the 24
-// P.V instructions while the VALU does max / exp / sum / pack of the next tile).  K tiles ride a 3-slot ring
-// (K(t+1) is needed while V(t) is), V tiles a 2-slot ring; one barrier per key tile.
-// =====================================================================================================
-template <int CT>
-__global__ __launch_bounds__(256, 2) void pam_fwd_pipe_kernel(const unsigned short* __restrict__ qt,
-                                                             const unsigned short* __restrict__ kt,
-                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
-                                                             const float* __restrict__ gamma, const float* __restrict__ x,
-                                                             long x_bs, float* __restrict__ out, long out_bs,
-                                                             float* __restrict__ o_attn, float* __restrict__ lse) {
-    constexpr int CP = CT * 32;
-    constexpr int KCH = F_KT * D_KROWCH;            // 320 chunks = 5 pieces per K tile
-    constexpr int KPIECE = KCH / 64;
-    constexpr int VCH = CP * D_VROWCH;
-    constexpr int VPIECE = (VCH + 63) / 64;
-    constexpr int NPIECE = KPIECE + VPIECE;
-    constexpr int PPW = (NPIECE + 3) / 4;
-    constexpr int KSLOT = KCH * 8;                  // elements per K slot
-    constexpr int VSLOT = VPIECE * 64 * 8;          // elements per V slot
-    __shared__ __attribute__((aligned(16))) unsigned short ring[3 * KSLOT + 2 * VSLOT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const unsigned short* ktb = kt + (long)b * Npad * 32;
-    const unsigned short* vb = v + (long)b * CP * Npad;
-
-    bf16x8_t qf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
-
-    const unsigned short* src[PPW];
-    bool live[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int piece = wave + 4 * i;
-        if (piece < KPIECE) {
-            const int c = piece * 64 + lane;
-            const int row = c / D_KROWCH, part = c - row * D_KROWCH;
-            src[i] = ktb + (long)row * 32 + (part < 4 ? part : 3) * 8;
-            live[i] = true;
-        } else {
-            const int c = (piece - KPIECE) * 64 + lane;
-            const int cc = c < VCH ? c : VCH - 1;
-            const int row = cc / D_VROWCH, part = cc - row * D_VROWCH;
-            src[i] = vb + (long)row * Npad + (part < 8 ? part : 7) * 8;
-            live[i] = piece < NPIECE && c < VCH;
-        }
-    }
-    // issue the K pieces of key tile tk (if >= 0) and the V pieces of key tile tv (if >= 0)
-    auto dma = [&](int tk, int tv) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int piece = wave + 4 * i;
-            if (piece < KPIECE) {
-                if (tk >= 0) {
-                    unsigned short* dst = ring + (tk % 3) * KSLOT + piece * 512;
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(src[i] + (long)tk * (F_KT * 32)),
-                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
-            } else if (live[i] && tv >= 0) {
-                unsigned short* dst = ring + 3 * KSLOT + (tv & 1) * VSLOT + (piece - KPIECE) * 512;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)tv * F_KT),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
-    };
-
-    f32x16_t o[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
-    float m = -1e30f, l = 0.f;
-    const int nkt = (N + F_KT - 1) / F_KT;
-
-    auto scores = [&](int t, f32x16_t (&sacc)[2]) {
-        const unsigned short* Ks = ring + (t % 3) * KSLOT;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
-                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
-            }
-        }
-        if ((t + 1) * F_KT > N) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
-        }
-    };
-    // online softmax of one score tile: returns the O rescale factor (1 when the max did not move), updates m, l,
-    // and leaves the packed bf16 probabilities in pf
-    auto softmax = [&](f32x16_t (&sacc)[2], bf16x8_t (&pf)[2][2]) -> float {
-        float mloc = sacc[0][0];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
-        const float m_new = fmaxf(m, mloc);
-        const float alpha = gd_exp2_fast(m - m_new);
-        m = m_new;
-        float lsum = 0.f;
-        const float neg_m = -m_new;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
-                sacc[sub][e] = p;
-                lsum += p;
-            }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l = l * alpha + lsum;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
-        return alpha;
-    };
-
-    // ---- prologue: K(0), V(0), K(1) in flight; scores + softmax of tile 0 ----
-    dma(0, 0);
-    if (nkt > 1) dma(1, -1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bf16x8_t pf_cur[2][2];
-    {
-        f32x16_t s0[2];
-        scores(0, s0);
-        (void)softmax(s0, pf_cur);   // O and l are still zero: the factor is irrelevant
-    }
-
-    for (int t = 0; t < nkt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K(t+1) / V(t) has landed
-        __syncthreads();                                    // ... everyone's has; K slot (t+2)%3 and V slot (t+1)&1 are free
-        dma(t + 2 < nkt ? t + 2 : -1, t + 1 < nkt ? t + 1 : -1);
-        const unsigned short* Vs = ring + 3 * KSLOT + (t & 1) * VSLOT;
-
-        float alpha = 1.f;
-        bf16x8_t pf_next[2][2];
-        const bool more = t + 1 < nkt;
-        f32x16_t sacc[2];
-        if (more) scores(t + 1, sacc);
-        // P(t).V(t) on the MFMA pipe; max / exp / sum / pack of tile t+1 on the VALU (independent of these MFMAs)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const unsigned short* vrow = Vs + (ct * 32 + r) * D_VLD;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    o[ct] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h), pf_cur[sub][s], o[ct]);
-        }
-        if (more) {
-            alpha = softmax(sacc, pf_next);
-            if (__any(alpha != 1.f)) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
-            }
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) pf_cur[sub][s] = pf_next[sub][s];
-        }
-    }
-
-    const int qi = q0 + r;
-    if (qi < N) {
-        const float inv_l = 1.f / l;
-        const float g = *gamma;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = ct * 32 + acc_row(e, h);
-                if (c < C) {
-                    const float val = o[ct][e] * inv_l;
-                    o_attn[((long)b * C + c) * N + qi] = val;
-                    out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
-                }
-            }
-        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
-    }
-}
-
-// =====================================================================================================
 // backward, part 1: dK^T and dV^T  (key-parallel; a workgroup owns NW*32 keys and sweeps the queries)
 // =====================================================================================================
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
@@ -777,191 +575,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
         for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
-}
-
-// =====================================================================================================
-// backward, part 1b: dK^T / dV^T with the channels split over wave pairs (even CT).
-//   8 waves = 4 key groups x 2 channel halves.  Both waves of a pair compute S; each accumulates dP over ITS
-//   half of the channels, the two partial dP tiles are exchanged through LDS, then each wave updates dV^T for
-//   its half of the channel tiles and one of the two k-steps of dK^T.  The accumulators of a wave shrink to
-//   (CT/2 + 1) tiles, so 8 waves (2 per SIMD) fit the 512-register file even at Cp = 192.
-// =====================================================================================================
-template <int CT>
-__global__ __launch_bounds__(512, 2) void pam_bwd_dkv_split_kernel(
-    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
-    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const unsigned short* __restrict__ don,
-    const float* __restrict__ lse, const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn,
-    float* __restrict__ dv) {
-    static_assert(CT % 2 == 0, "channel tiles are split in two halves");
-    constexpr int CP = CT * 32;
-    constexpr int HT = CT / 2;                     // channel tiles per wave
-    constexpr int NT = 512;
-    constexpr int DLD = CP + 8;
-    constexpr int NCHUNK = 256 + 256 * CT;
-    constexpr int NPRE = (NCHUNK + NT - 1) / NT;
-    constexpr bool RAGGED = (NCHUNK % NT) != 0;    // last pass only covers part of the threads
-    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
-    __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
-    __shared__ float Xs[8 * 16 * 64];              // partial-dP exchange: [wave][register][lane]
-    __shared__ float Ls[32], Ds[32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int kg = wave >> 1, half = wave & 1;
-    const int b = blockIdx.y;
-    const int j0 = blockIdx.x * 128 + kg * 32;
-    const long nb = (long)b * Npad;
-
-    bf16x8_t kfB[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
-    bf16x8_t vfB[CT];   // this wave's half of the channel k-steps of dP = dO V^T
-#pragma unroll
-    for (int s = 0; s < CT; ++s)
-        vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + (half * CT + s) * 16 + 8 * h);
-
-    f32x16_t dvacc[HT], dkacc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dkacc[e] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < HT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
-
-    const bool key_ok = (j0 + r) < N;
-    const bool need_mask = (int)(blockIdx.x + 1) * 128 > N;
-    const int nqt = (N + 31) / 32;
-
-    // ---- staging plan, fixed per thread: source pointer at tile 0, elements to advance per tile, LDS slot ----
-    const unsigned short* src[NPRE];
-    int step[NPRE];
-    unsigned short* dst[NPRE];
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-        int c = tid + k * NT;
-        if (RAGGED && k == NPRE - 1 && c >= NCHUNK) c = 0;   // parked on a valid chunk, never stored
-        if (c < 128) {
-            src[k] = qt + (nb + (c >> 2)) * 32 + (c & 3) * 8;  step[k] = 32 * 32;
-            dst[k] = Qs + (c >> 2) * B_QLD + (c & 3) * 8;
-        } else if (c < 256) {
-            const int c2 = c - 128;
-            src[k] = qn + ((long)b * 32 + (c2 >> 2)) * Npad + (c2 & 3) * 8;  step[k] = 32;
-            dst[k] = QTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8;
-        } else if (c < 256 + 128 * CT) {
-            const int c2 = c - 256;
-            const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
-            src[k] = dot_ + (nb + i) * CP + ch * 8;  step[k] = 32 * CP;
-            dst[k] = dOs + i * DLD + ch * 8;
-        } else {
-            const int c2 = c - 256 - 128 * CT;
-            src[k] = don + ((long)b * CP + (c2 >> 2)) * Npad + (c2 & 3) * 8;  step[k] = 32;
-            dst[k] = dOTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8;
-        }
-    }
-    const bool last_ok = !RAGGED || (tid + (NPRE - 1) * NT) < NCHUNK;
-
-    u32x4_t pre[NPRE];
-    float pre_s = 0.f;
-    auto load_tile = [&](int qtile) {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k)
-            pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
-        if (tid < 64) {
-            const int i = qtile * 32 + (tid & 31);
-            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;   // negated once here
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            if (k < NPRE - 1 || last_ok) {   // every slot is 8-byte aligned: two 8-byte stores serve all four regions
-                u32x2_t* d2 = reinterpret_cast<u32x2_t*>(dst[k]);
-                d2[0] = u32x2_t{pre[k].x, pre[k].y};
-                d2[1] = u32x2_t{pre[k].z, pre[k].w};
-            }
-        }
-        if (tid < 32) Ls[tid] = pre_s;
-        else if (tid < 64) Ds[tid - 32] = pre_s;
-    };
-
-    float* xmine = Xs + wave * (16 * 64) + lane;
-    const float* xpart = Xs + (wave ^ 1) * (16 * 64) + lane;
-
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-
-    for (int qtile = 0; qtile < nqt; ++qtile) {
-        const int i0 = qtile * 32;
-        if (qtile + 1 < nqt) load_tile(qtile + 1);
-
-        f32x16_t sacc, dpacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            sacc[e] = Ls[acc_row(e, h)];
-            dpacc[e] = half == 0 ? Ds[acc_row(e, h)] : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
-            sacc = mfma_bf16(qa, kfB[s], sacc);
-        }
-#pragma unroll
-        for (int s = 0; s < CT; ++s) {
-            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + (half * CT + s) * 16 + 8 * h);
-            dpacc = mfma_bf16(da, vfB[s], dpacc);
-        }
-        // ---- exchange the partial dP tiles inside the wave pair ----
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xmine[e * 64] = dpacc[e];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dpacc[e] += xpart[e * 64];
-
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
-        if (need_mask || i0 + 32 > N) {   // workgroup-uniform: padded keys in this block, or the ragged last query tile
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (!(key_ok && (i0 + acc_row(e, h)) < N)) sacc[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dpacc[e] *= sacc[e];   // dS = P (dP - delta)
-        bf16x8_t pf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) pf[s] = pack_frag(sacc, s);
-#pragma unroll
-        for (int ct = 0; ct < HT; ++ct) {
-            const unsigned short* row = dOTs + ((half * HT + ct) * 32 + r) * B_TLD;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_perm_frag(row, s * 16, h), pf[s], dvacc[ct]);
-        }
-        // dK^T: this wave takes k-step `half` (queries 16*half .. 16*half+15 of the tile); the partner the other
-        dkacc = mfma_bf16(read_perm_frag(QTs + r * B_TLD, half * 16, h),
-                          half == 0 ? pack_frag(dpacc, 0) : pack_frag(dpacc, 1), dkacc);
-        __syncthreads();  // tile and exchange buffer fully consumed
-        if (qtile + 1 < nqt) {
-            store_tile();
-            __syncthreads();
-        }
-    }
-
-    const int j = j0 + r;
-#pragma unroll
-    for (int ct = 0; ct < HT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            dv[((long)b * CP + (half * HT + ct) * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
-    // dK^T = sum of the pair's two k-step halves
-#pragma unroll
-    for (int e = 0; e < 16; ++e) xmine[e * 64] = dkacc[e];
-    __syncthreads();
-    if (half == 0) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e] + xpart[e * 64];
-    }
 }
 
 // =====================================================================================================
@@ -1270,17 +883,12 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
     dim3 grid(Npad / 128, B);
     static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 1;
-    if (dma_env == 2) {
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_pipe_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                     (const unsigned short*)qt, (const unsigned short*)kt,
-                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
-                                                     o_attn, lse));
-    } else if (dma_env) {
+    if (dma_env) {   // default: LDS-DMA ring (no staging registers, one barrier per key tile)
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
                                                      o_attn, lse));
-    } else {
+    } else {         // GD_PAM_FWD_DMA=0: register-staged variant (A/B reference)
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
@@ -1299,19 +907,14 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, 
     hipStream_t s = (hipStream_t)stream;
     // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
     // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
-    static const int split_env = getenv("GD_PAM_DKV_SPLIT") ? atoi(getenv("GD_PAM_DKV_SPLIT")) : 0;
     static const int v3_env = getenv("GD_PAM_DKV_V3") ? atoi(getenv("GD_PAM_DKV_V3")) : 1;
-    GD_CHECK_ARG(v3_env || (qn && don), "gd_pam_flash_bwd: qn/don are required by the non-default dK/dV variants");
-    if (v3_env) {                   // transpose-read variant: 4 waves, two independent workgroups per CU
+    GD_CHECK_ARG(v3_env || (qn && don), "gd_pam_flash_bwd: qn/don are required by the GD_PAM_DKV_V3=0 dK/dV variant");
+    if (v3_env) {                   // default: transpose-read variant, 4 waves, two independent workgroups per CU
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)vt, (const unsigned short*)dot_, lse, delta,
                                                      N, Npad, dkn, dv));
-    } else if (Cp == 192 && split_env) {   // alternative for Cp = 192: channel halves split over wave pairs (A/B switch)
-        hipLaunchKernelGGL((pam_bwd_dkv_split_kernel<6>), dim3(Npad / 128, B), dim3(512), 0, s, (const unsigned short*)qt,
-                           (const unsigned short*)kt, (const unsigned short*)qn, (const unsigned short*)vt,
-                           (const unsigned short*)dot_, (const unsigned short*)don, lse, delta, N, Npad, dkn, dv);
-    } else if (Cp == 192) {         // 12 V fragments per lane do not fit beside 7 accumulator tiles: V rows live in LDS
+    } else if (Cp == 192) {         // A/B reference: 8-wave kernel staging q^T / dO^T copies; V rows in LDS at Cp = 192
         hipLaunchKernelGGL((pam_bwd_dkv_kernel<6, 8, true>), dim3(Npad / 256, B), dim3(512), 0, s,
                            (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)qn,
                            (const unsigned short*)vt, (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,

@@ -288,3 +288,42 @@ def test_pam_fused_other_widths_vs_oracle(gd, c, hw):
     po, pg = dict(mo.named_parameters()), dict(m.named_parameters())
     for n in ("query.weight", "key.weight", "value.weight", "value.bias", "query.bias", "gamma"):
         assert_close(pg[n].grad, po[n].grad, 5e-2, n, rell2)
+
+
+def test_pam_fused_ragged_inference_size(gd):
+    """N = 45*22 = 990 pixels (the reference's 0.25-degree inference grid, test.ipynb): not a multiple of the
+    32-query / 64-key / 256-pad tiles -> exercises key masking and partial query tiles; forward only."""
+    from gan_danet_amd.generator import PAMModule
+    from oracle import modules as OM
+    c = 64
+    mo = OM.PAMModule(c)
+    fill_module(mo)
+    with torch.no_grad():
+        mo.gamma.fill_(0.5)
+    x = bf16_round(seeded((2, c, 45, 22), 83))
+    with torch.no_grad():
+        yo = mo(x)
+    m = PAMModule(c)
+    m.load_state_dict(mo.state_dict())
+    m.to(DEV)
+    with gd.precision("bf16"), torch.no_grad():
+        y = m(x.to(DEV))
+    assert_close(y, yo, 2e-2, "ragged N forward")
+
+
+def test_conv3x3_full_size_shift_property(gd):
+    """size-independent property at the bench's largest map (1024 x 1024): a 3x3 kernel that is a one-hot tap is a
+    pure shift -- checked exactly (bf16-representable data) on the LDS-patch kernel, borders included."""
+    from gan_danet_amd import _lib as L
+    from gan_danet_amd import kern as K
+    x = bf16_round(seeded((1, 2, 1024, 1024), 84)).to(DEV)
+    w = torch.zeros(2, 2, 3, 3)
+    w[0, 1, 0, 2] = 1.0     # out0[y][x] = in1[y-1][x+1]
+    w[1, 0, 2, 1] = 1.0     # out1[y][x] = in0[y+1][x]
+    y = K.conv2d_fwd(x, w.to(DEV), None, 1, 1, L.PREC_BF16).cpu()
+    xc = x.cpu()
+    ref0 = torch.zeros(1024, 1024)
+    ref0[1:, :-1] = xc[0, 1, :-1, 1:]
+    ref1 = torch.zeros(1024, 1024)
+    ref1[:-1, :] = xc[0, 0, 1:, :]
+    assert torch.equal(y[0, 0], ref0) and torch.equal(y[0, 1], ref1)
