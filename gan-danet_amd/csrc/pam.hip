@@ -230,25 +230,30 @@ constexpr int D_KROWCH = 5;                 // 16-byte chunks per K row (80 B)
 constexpr int D_VROWCH = 9;                 // 16-byte chunks per V row (144 B)
 constexpr int D_VLD = D_VROWCH * 8;         // 72 elements
 
-template <int CT>
-__global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned short* __restrict__ qt,
+// NW waves = NW*32 queries per workgroup share each staged K/V tile (8 waves: half the L2 -> LDS streaming per query)
+// KT keys per staged tile (64 or 128: fewer barriers and DMA issue rounds per key, more independent work per wave)
+template <int CT, int NW, int KT = 64>
+__global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned short* __restrict__ qt,
                                                             const unsigned short* __restrict__ kt,
                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ x,
                                                             long x_bs, float* __restrict__ out, long out_bs,
                                                             float* __restrict__ o_attn, float* __restrict__ lse) {
     constexpr int CP = CT * 32;
-    constexpr int KCH = F_KT * D_KROWCH;            // 320 chunks of K
-    constexpr int NCH = KCH + CP * D_VROWCH;        // + V chunks
+    constexpr int NSUB = KT / 32;                   // 32-key sub-tiles per staged tile
+    constexpr int VROWCH = KT / 8 + 1;              // 16-byte chunks per V row (data + 1 pad)
+    constexpr int VLD = KT + 8;
+    constexpr int KCH = KT * D_KROWCH;              // chunks of K
+    constexpr int NCH = KCH + CP * VROWCH;          // + V chunks
     constexpr int NPIECE = (NCH + 63) / 64;         // 1-KiB DMA pieces per tile
-    constexpr int PPW = (NPIECE + 3) / 4;           // pieces per wave
+    constexpr int PPW = (NPIECE + NW - 1) / NW;     // pieces per wave
     constexpr int TILE = NPIECE * 64 * 8;           // elements per ring slot
     __shared__ __attribute__((aligned(16))) unsigned short ring[2 * TILE];   // the ONLY LDS object (DMA + ds_read)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const unsigned short* ktb = kt + (long)b * Npad * 32;
     const unsigned short* vb = v + (long)b * CP * Npad;
 
@@ -263,25 +268,25 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
     bool live[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int piece = wave + 4 * i;
+        const int piece = wave + NW * i;
         const int c = piece * 64 + lane;
         live[i] = piece < NPIECE && c < NCH;
         if (c < KCH) {
             const int row = c / D_KROWCH, part = c - row * D_KROWCH;
             src[i] = ktb + (long)row * 32 + (part < 4 ? part : 3) * 8;
-            adv[i] = F_KT * 32;
+            adv[i] = KT * 32;
         } else {
             const int c2 = (c < NCH ? c : NCH - 1) - KCH;
-            const int row = c2 / D_VROWCH, part = c2 - row * D_VROWCH;
-            src[i] = vb + (long)row * Npad + (part < 8 ? part : 7) * 8;
-            adv[i] = F_KT;
+            const int row = c2 / VROWCH, part = c2 - row * VROWCH;
+            src[i] = vb + (long)row * Npad + (part < KT / 8 ? part : KT / 8 - 1) * 8;
+            adv[i] = KT;
         }
     }
     auto dma_tile = [&](int t, int slot) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             if (live[i]) {
-                unsigned short* dst = ring + slot * TILE + (wave + 4 * i) * 512;   // wave-uniform piece base
+                unsigned short* dst = ring + slot * TILE + (wave + NW * i) * 512;   // wave-uniform piece base
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)t * adv[i]),
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
     float m = -1e30f, l = 0.f;
-    const int nkt = (N + F_KT - 1) / F_KT;
+    const int nkt = (N + KT - 1) / KT;
 
     dma_tile(0, 0);
     for (int t = 0; t < nkt; ++t) {
@@ -306,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
         const unsigned short* Ks = ring + (t & 1) * TILE;
         const unsigned short* Vs = Ks + KCH * 8;
 
-        f32x16_t sacc[2];
+        f32x16_t sacc[NSUB];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
 #pragma unroll
@@ -317,16 +322,16 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
                 sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
             }
         }
-        if ((t + 1) * F_KT > N) {
+        if ((t + 1) * KT > N) {   // wave-uniform: only the last tile masks padded keys
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
+                    if ((t * KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
         }
         float mloc = sacc[0][0];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
         float lsum = 0.f;
         const float neg_m = -m;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
@@ -353,19 +358,35 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_dma_kernel(const unsigned shor
         lsum += __shfl_xor(lsum, 32, 64);
         l += lsum;
 
-        bf16x8_t pf[2][2];
+        bf16x8_t pf[NSUB][2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
+        // V fragments are read in batches of FB ahead of the MFMAs that consume them (the scheduler is pinned with
+        // sched_group_barrier: FB LDS reads, then FB MFMAs), so one LDS round trip is paid per batch, not per MFMA
+        constexpr int FB = 8, NF = 2 * NSUB * CT;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const unsigned short* vrow = Vs + (ct * 32 + r) * D_VLD;
+        for (int f0 = 0; f0 < NF; f0 += FB) {
+            bf16x8_t vf[FB];
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int i = 0; i < FB; ++i) {
+                const int f = f0 + i;
+                if (f < NF) {
+                    const int ct = f / (2 * NSUB), sub = (f >> 1) % NSUB, s2 = f & 1;
+                    vf[i] = *reinterpret_cast<const bf16x8_t*>(Vs + (ct * 32 + r) * VLD + sub * 32 + s2 * 16 + 8 * h);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, FB, 0);   // DS reads
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    o[ct] = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h), pf[sub][s], o[ct]);
+            for (int i = 0; i < FB; ++i) {
+                const int f = f0 + i;
+                if (f < NF) {
+                    const int ct = f / (2 * NSUB), sub = (f >> 1) % NSUB, s2 = f & 1;
+                    o[ct] = mfma_bf16(vf[i], pf[sub][s2], o[ct]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, FB, 0);   // MFMAs
         }
     }
 
@@ -882,9 +903,21 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 128 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
     dim3 grid(Npad / 128, B);
-    static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 1;
-    if (dma_env) {   // default: LDS-DMA ring (no staging registers, one barrier per key tile)
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
+    // default 16: LDS-DMA ring, 8 waves (256 queries) per workgroup, 128-key tiles; 8 / 1: 64-key tiles with 8 / 4
+    // waves; 0: register-staged 4-wave kernel.  Measured at B=4, N=65536, C=184: 7.72 / 7.82 / 8.43 / 8.75 ms.
+    static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 16;
+    if (dma_env == 16 && Npad % 256 == 0) {  // 8 waves, 128-key tiles
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0,
+                                                     (hipStream_t)stream, (const unsigned short*)qt,
+                                                     (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C,
+                                                     gamma, x, x_bs, out, out_bs, o_attn, lse));
+    } else if (dma_env == 8 && Npad % 256 == 0) {   // 8 waves = 256 queries per workgroup
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0,
+                                                     (hipStream_t)stream, (const unsigned short*)qt,
+                                                     (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C,
+                                                     gamma, x, x_bs, out, out_bs, o_attn, lse));
+    } else if (dma_env) {   // default: LDS-DMA ring (no staging registers, one barrier per key tile)
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 4>), grid, dim3(256), 0, (hipStream_t)stream,
                                                      (const unsigned short*)qt, (const unsigned short*)kt,
                                                      (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
                                                      o_attn, lse));
