@@ -769,29 +769,34 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
 }
 
 // =====================================================================================================
-// backward, part 2: dQ^T  (query-parallel like the forward: a workgroup owns 128 queries and streams keys)
+// backward, part 2: dQ^T  (query-parallel like the forward: a workgroup owns NW*32 queries and streams keys)
 //   S^T[j][i], dP^T[j][i] with the key on the accumulator rows and the query on the lane (lse/delta are lane
 //   constants), dS^T is the B operand of dQ^T[d][i] += K^T[d][j] dS^T[j][i]; dQ^T accumulates in registers --
 //   no atomics, deterministic, and it is stored channel-major (the layout the projection gradients read).
+//   K [key][d], K^T [d][key] (keys perm16-ordered) and V [key][c] tiles arrive by LDS-DMA into a 2-slot ring.
 // =====================================================================================================
-constexpr int Q_KT = 64;
-constexpr int Q_KNLD = 68;   // K^T rows [d][64 keys] + 4 pad (136 B): conflict-free 8-byte permuted reads
-
-template <int CT>
-__global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
+template <int CT, int NW, int KT>
+__global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ lse,
     const float* __restrict__ delta, int N, int Npad, float* __restrict__ dqn) {
     constexpr int CP = CT * 32;
-    constexpr int VLD = CP + 8;   // V tile rows [key][CP c]: 16-B reads conflict free
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[Q_KT * F_KLD];    // K rows [key][32 d]
-    __shared__ __attribute__((aligned(16))) unsigned short KNs[32 * Q_KNLD];     // K^T rows [d][64 keys]
-    __shared__ __attribute__((aligned(16))) unsigned short VTs[Q_KT * VLD];     // V rows [key][CP c]
+    constexpr int NSUB = KT / 32;
+    constexpr int KNROWCH = KT / 8 + 1, KNLD = KT + 8;     // K^T rows [d][KT keys] + 16 B pad
+    constexpr int VROWCH = CP / 8 + 1, VLD = CP + 8;       // V rows [key][CP c] + 16 B pad
+    constexpr int KCH = KT * D_KROWCH;
+    constexpr int NCHN = 32 * KNROWCH;
+    constexpr int VCH = KT * VROWCH;
+    constexpr int NCH = KCH + NCHN + VCH;
+    constexpr int NPIECE = (NCH + 63) / 64;
+    constexpr int PPW = (NPIECE + NW - 1) / NW;
+    constexpr int TILE = NPIECE * 64 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned short ring[2 * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const long nb = (long)b * Npad;
     const int qi = q0 + r;
 
@@ -804,44 +809,59 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
     const float nlse = qi < N ? -lse[(long)b * N + qi] * LOG2E : 0.f;   // log2 domain
     const float ndelta = qi < N ? -delta[(long)b * N + qi] : 0.f;
 
+    // ---- DMA plan of this lane ----
+    const unsigned short* src[PPW];
+    int adv[PPW];
+    bool live[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + NW * i;
+        int c = piece * 64 + lane;
+        live[i] = piece < NPIECE && c < NCH;
+        if (c >= NCH) c = NCH - 1;
+        if (c < KCH) {
+            const int row = c / D_KROWCH, part = c - row * D_KROWCH;
+            src[i] = kt + (nb + row) * 32 + (part < 4 ? part : 3) * 8;
+            adv[i] = KT * 32;
+        } else if (c < KCH + NCHN) {
+            const int c2 = c - KCH;
+            const int row = c2 / KNROWCH, part = c2 - row * KNROWCH;
+            src[i] = kn + ((long)b * 32 + row) * Npad + (part < KT / 8 ? part : KT / 8 - 1) * 8;
+            adv[i] = KT;
+        } else {
+            const int c3 = c - KCH - NCHN;
+            const int row = c3 / VROWCH, part = c3 - row * VROWCH;
+            src[i] = vt + (nb + row) * CP + (part < CP / 8 ? part : CP / 8 - 1) * 8;
+            adv[i] = KT * CP;
+        }
+    }
+    auto dma_tile = [&](int t, int slot) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (live[i]) {
+                unsigned short* dst = ring + slot * TILE + (wave + NW * i) * 512;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)t * adv[i]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
     f32x16_t dq;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[e] = 0.f;
 
-    const int nkt = (N + Q_KT - 1) / Q_KT;
-    u32x4_t kreg, knreg, vreg[CT];
-    auto load_tile = [&](int t) {
-        const int k0 = t * Q_KT;
-        kreg = *reinterpret_cast<const u32x4_t*>(kt + (nb + k0 + (tid >> 2)) * 32 + (tid & 3) * 8);
-        knreg = *reinterpret_cast<const u32x4_t*>(kn + ((long)b * 32 + (tid >> 3)) * Npad + k0 + (tid & 7) * 8);
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (4 * CT), ch = idx - row * (4 * CT);
-            vreg[i] = *reinterpret_cast<const u32x4_t*>(vt + (nb + k0 + row) * CP + ch * 8);
-        }
-    };
-    auto store_tile = [&]() {
-        *reinterpret_cast<u32x4_t*>(Ks + (tid >> 2) * F_KLD + (tid & 3) * 8) = kreg;
-        u32x2_t* kd = reinterpret_cast<u32x2_t*>(KNs + (tid >> 3) * Q_KNLD + (tid & 7) * 8);
-        kd[0] = u32x2_t{knreg.x, knreg.y};
-        kd[1] = u32x2_t{knreg.z, knreg.w};
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (4 * CT), ch = idx - row * (4 * CT);
-            *reinterpret_cast<u32x4_t*>(VTs + row * VLD + ch * 8) = vreg[i];
-        }
-    };
-
-    load_tile(0);
-    store_tile();
-    __syncthreads();
+    const int nkt = (N + KT - 1) / KT;
+    dma_tile(0, 0);
     for (int t = 0; t < nkt; ++t) {
-        if (t + 1 < nkt) load_tile(t + 1);
-        const bool tail = (t + 1) * Q_KT > N;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see pam_fwd_dma_kernel: the DMA wait is ours to place
+        __syncthreads();
+        if (t + 1 < nkt) dma_tile(t + 1, (t + 1) & 1);
+        const unsigned short* Ks = ring + (t & 1) * TILE;
+        const unsigned short* KNs = Ks + KCH * 8;
+        const unsigned short* VTs = KNs + NCHN * 8;
+        const bool tail = (t + 1) * KT > N;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             f32x16_t sacc, dpacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -853,10 +873,20 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
                 sacc = mfma_bf16(kf, qf[s], sacc);
             }
+            // V fragments in batches ahead of their MFMAs (one LDS round trip per batch)
+            constexpr int FB = 6;
 #pragma unroll
-            for (int s = 0; s < 2 * CT; ++s) {
-                const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(VTs + (sub * 32 + r) * VLD + s * 16 + 8 * h);
-                dpacc = mfma_bf16(va, dof[s], dpacc);
+            for (int s0 = 0; s0 < 2 * CT; s0 += FB) {
+                bf16x8_t va[FB];
+#pragma unroll
+                for (int i = 0; i < FB; ++i)
+                    if (s0 + i < 2 * CT)
+                        va[i] = *reinterpret_cast<const bf16x8_t*>(VTs + (sub * 32 + r) * VLD + (s0 + i) * 16 + 8 * h);
+                __builtin_amdgcn_sched_group_barrier(0x100, FB, 0);
+#pragma unroll
+                for (int i = 0; i < FB; ++i)
+                    if (s0 + i < 2 * CT) dpacc = mfma_bf16(va[i], dof[s0 + i], dpacc);
+                __builtin_amdgcn_sched_group_barrier(0x008, FB, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -866,17 +896,12 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dq_kernel(
             if (tail) {   // wave-uniform: padded keys of the last tile contribute nothing
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if ((t * Q_KT + sub * 32 + acc_row(e, h)) >= N) dpacc[e] = 0.f;
+                    if ((t * KT + sub * 32 + acc_row(e, h)) >= N) dpacc[e] = 0.f;
             }
-            const unsigned short* krow = KNs + r * Q_KNLD;
+            const unsigned short* krow = KNs + r * KNLD;   // K^T row d = r, keys perm16-ordered: one 16-byte read
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                dq = mfma_bf16(read_perm_frag(krow, sub * 32 + s * 16, h), pack_frag(dpacc, s), dq);
-        }
-        __syncthreads();
-        if (t + 1 < nkt) {
-            store_tile();
-            __syncthreads();
+                dq = mfma_bf16(*reinterpret_cast<const bf16x8_t*>(krow + sub * 32 + s * 16 + 8 * h), pack_frag(dpacc, s), dq);
         }
     }
 #pragma unroll
@@ -959,7 +984,8 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, 
                                                      (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
                                                      N, Npad, dkn, dv));
     }
-    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
+    // dQ: 8 waves (256 queries) per workgroup, 128-key LDS-DMA tiles; kn must be packed perm16 along the keys
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0, s,
                                                  (const unsigned short*)qt, (const unsigned short*)kt,
                                                  (const unsigned short*)kn, (const unsigned short*)vt,
                                                  (const unsigned short*)dot_, lse, delta, N, Npad, dqn));

@@ -226,7 +226,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
     if fused:
         Np, Cp = _npad(N), _cp(Cn)
         qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np) if _LEGACY_DKV else None, t_shape=(Np, 32))
-        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
+        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True)
         vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True)
         del q, k, v
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)

@@ -219,7 +219,7 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                      const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn,
                      float* lse, void* stream);
-/* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad); vt (B,Npad,Cp);
+/* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad) (kn perm16-ordered); vt (B,Npad,Cp);
  * dot (B,Npad,Cp) and don (B,Cp,Npad) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
  * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad).  Two launches: a key-parallel
  * kernel for dK/dV and a query-parallel kernel for dQ (no atomics: bitwise reproducible).  Npad % 256 == 0.

@@ -29,7 +29,7 @@ x = torch.randn(B, C, N, device=dev, generator=g)
 do = torch.randn(B, C, N, device=dev, generator=g)
 gamma = torch.full((1,), 0.1, device=dev)
 qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
-kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
+kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True)
 vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True)
 out, o = torch.empty_like(x), torch.empty_like(x)
 lse = torch.empty(B, N, device=dev)
