@@ -43,14 +43,17 @@ __global__ void pack_w_kernel(const float* __restrict__ a, long a_sm, long a_sc,
     }
 }
 
-template <int BM, int TH>
+// S = convolution stride (1, or 2 for the down-sampling convs of the discriminator: the patch then covers
+// (2TH+1) x 65 input pixels and consecutive output pixels read patch rows two apart)
+template <int BM, int TH, int S>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc d, const unsigned short* __restrict__ wp,
                                                              int tiles_x, int nchunks) {
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int TM = BM / (32 * WAVES_M);       // 32-row m-tiles per wave
     constexpr int TN = TH / WAVES_N;              // image rows (n-tiles) per wave
-    constexpr int PH = TH + 2;
-    constexpr int NPIX = PH * PW;
+    constexpr int PH = S * (TH - 1) + 3;
+    constexpr int PWk = S * (TW - 1) + 3;
+    constexpr int NPIX = PH * PWk;
     constexpr int WCHUNKS = 3 * BM * CK / 8;      // 16-byte vectors of one kernel row of weights
     constexpr int WPT = WCHUNKS / 256;            // per thread
     static_assert(WCHUNKS % 256 == 0, "weight stage must divide evenly");
@@ -65,8 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
     const int mt = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int H = d.Hi, W = d.Wi;
-    const long HW = (long)H * W;
+    const int H = d.Hi, W = d.Wi;            // input size
+    const int Ho = d.Ho, Wo = d.Wo;          // output size
+    const long HW = (long)H * W, HWo = (long)Ho * Wo;
     const float* ximg = d.x + (long)b * d.x_bs;
 
     f32x16_t acc[TM][TN];
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
         for (int w = tid; w < 2 * NPIX; w += 256) {
             const int half = w >= NPIX ? 1 : 0;
             const int pix = w - half * NPIX;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const int py = pix / PWk, px = pix - py * PWk;
+            const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
             const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
             const int cb = c0 + half * 16;
             const float* p = ximg + (long)cb * HW + (long)iy * W + ix;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
                                                                   ks * 16 + 8 * h);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + ((wn * TN + j + ky) * PW + r + kx) * LD +
+                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + (((wn * TN + j) * S + ky) * PWk + r * S + kx) * LD +
                                                                   ks * 16 + 8 * h);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -162,12 +166,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
     // ---- epilogue (same contract as gd_conv2d: alpha, bias, residual, activation, accumulate) ----
     const float alpha = d.alpha ? *d.alpha : 1.f;
     const int ox = x0 + r;
-    if (ox < W) {
+    if (ox < Wo) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int oy = y0 + wn * TN + j;
-            if (oy >= H) continue;
-            const long pn = (long)oy * W + ox;
+            if (oy >= Ho) continue;
+            const long pn = (long)oy * Wo + ox;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -176,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
                     if (m >= d.M) continue;
                     float v = acc[i][j][e] * alpha;
                     if (d.bias) v += d.bias[m];
-                    if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HW + pn];
+                    if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HWo + pn];
                     if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
-                    float* yp = reinterpret_cast<float*>(d.y) + (long)b * d.y_bs + (long)m * HW + pn;
+                    float* yp = reinterpret_cast<float*>(d.y) + (long)b * d.y_bs + (long)m * HWo + pn;
                     if (d.accumulate) v += *yp;
                     *yp = v;
                 }
@@ -197,14 +201,17 @@ extern "C" size_t gd_conv3x3_ws_bytes(int M, int Ck) {
 
 // returns 1 when the descriptor is served by this kernel, 0 when the caller should use the generic one
 extern "C" int gd_conv3x3_eligible(const gd_conv_desc* d) {
-    return d && d->ks == 3 && d->stride == 1 && d->pad == 1 && d->out_layout == 0 && !d->out_bf16 &&
-           d->precision == GD_PREC_BF16 && d->a_bs == 0 && d->Hi == d->Ho && d->Wi == d->Wo &&
-           (d->Mstore == 0 || d->Mstore == d->M);
+    if (!(d && d->ks == 3 && d->pad == 1 && d->out_layout == 0 && !d->out_bf16 && d->precision == GD_PREC_BF16 &&
+          d->a_bs == 0 && (d->Mstore == 0 || d->Mstore == d->M) && d->sub_step <= 1))
+        return 0;
+    if (d->stride == 1) return d->Hi == d->Ho && d->Wi == d->Wo;
+    // stride 2: forward gather only (its data gradient is split by output parity on the generic kernel)
+    return d->stride == 2 && !d->transposed && (d->Hi - 1) / 2 + 1 == d->Ho && (d->Wi - 1) / 2 + 1 == d->Wo;
 }
 
 extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, void* stream) {
     GD_CHECK_ARG(dp && ws, "gd_conv3x3: null argument");
-    GD_CHECK_ARG(gd_conv3x3_eligible(dp), "gd_conv3x3: descriptor not eligible (needs 3x3, stride 1, pad 1, bf16, fp32 NCHW out)");
+    GD_CHECK_ARG(gd_conv3x3_eligible(dp), "gd_conv3x3: descriptor not eligible (needs 3x3, pad 1, stride 1 or forward stride 2, bf16, fp32 NCHW out)");
     const gd_conv_desc& d = *dp;
     GD_CHECK_ARG(d.B > 0 && d.B <= 65535 && d.M > 0 && d.Ck > 0 && d.Hi > 0 && d.Wi > 0, "gd_conv3x3: bad sizes");
     GD_CHECK_ARG(d.a && d.x && d.y, "gd_conv3x3: null tensor");
@@ -220,14 +227,18 @@ extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, voi
         hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, s, d.a, d.a_sm, d.a_sc, d.a_st, d.M, d.Ck,
                            d.transposed ? 1 : 0, bm, nchunks, (unsigned short*)ws, total);
     }
-    constexpr int TH = 8;
-    const int tiles_x = (d.Wi + TW - 1) / TW, tiles_y = (d.Hi + TH - 1) / TH;
+    const int th = d.stride == 1 ? 8 : 4;   // stride 2 patches are 4x larger per output row: 4-row tiles keep 2 blocks/CU
+    const int tiles_x = (d.Wo + TW - 1) / TW, tiles_y = (d.Ho + th - 1) / th;
     GD_CHECK_ARG((long)tiles_x * tiles_y < (1L << 31), "gd_conv3x3: image too large");
     dim3 grid(tiles_x * tiles_y, mtiles, d.B);
-    if (bm == 64)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<64, TH>), grid, dim3(256), 0, s, d, (const unsigned short*)ws, tiles_x, nchunks);
-    else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<128, TH>), grid, dim3(256), 0, s, d, (const unsigned short*)ws, tiles_x, nchunks);
+    const unsigned short* wpk = (const unsigned short*)ws;
+    if (d.stride == 1) {
+        if (bm == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 8, 1>), grid, dim3(256), 0, s, d, wpk, tiles_x, nchunks);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<128, 8, 1>), grid, dim3(256), 0, s, d, wpk, tiles_x, nchunks);
+    } else {
+        if (bm == 64) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 4, 2>), grid, dim3(256), 0, s, d, wpk, tiles_x, nchunks);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<128, 4, 2>), grid, dim3(256), 0, s, d, wpk, tiles_x, nchunks);
+    }
     GD_LAUNCH_CHECK();
     return 0;
 }
