@@ -267,7 +267,7 @@ struct WgradArgs {
     const float* x; long x_bs;
     const float* in_scale; const float* in_shift; int in_relu;
     float* dw;
-    int B, M, Ck, H, W;
+    int B, M, Ck, H, W, Ho, Wo;
     int tiles_x, tiles_y, tiles_per_split;
 };
 
@@ -275,17 +275,19 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
-template <int NW>
+template <int NW, int S>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int BM = 32 * NW, NT = 64 * NW;
+    constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
     __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
-    __shared__ __attribute__((aligned(16))) unsigned short patch[WNPIX * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short patch[NPIXk * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int c0 = blockIdx.x * CK;
     const int m0 = blockIdx.y * BM;
-    const long HW = (long)a.H * a.W;
+    const long HW = (long)a.H * a.W;            // input plane
+    const long HWo = (long)a.Ho * a.Wo;         // output (dY) plane
     const int ntiles = a.B * a.tiles_y * a.tiles_x;
     const int t_begin = blockIdx.z * a.tiles_per_split;
     const int t_end = min(ntiles, t_begin + a.tiles_per_split);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
     // transpose-read lane roles: group of 16 lanes = one 4(k) x 16(n) block; lane 4q+pp supplies row q, cols 4pp..
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
-    const bool vec_ok = (a.W % 4) == 0;
+    const bool vec_ok = (a.Wo % 4) == 0;
 
     for (int t = t_begin; t < t_end; ++t) {
         const int b = t / (a.tiles_y * a.tiles_x);
@@ -315,15 +317,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             const int m = idx >> 5, v = idx & 31;
             const int yy = y0 + (v >> 3), xx = x0 + (v & 7) * 4;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + m < a.M && yy < a.H) {
-                const float* p = dyb + (long)(m0 + m) * HW + (long)yy * a.W + xx;
-                if (vec_ok && xx + 3 < a.W) {
+            if (m0 + m < a.M && yy < a.Ho) {
+                const float* p = dyb + (long)(m0 + m) * HWo + (long)yy * a.Wo + xx;
+                if (vec_ok && xx + 3 < a.Wo) {
                     f = *reinterpret_cast<const float4*>(p);
                 } else {
-                    if (xx + 0 < a.W) f.x = p[0];
-                    if (xx + 1 < a.W) f.y = p[1];
-                    if (xx + 2 < a.W) f.z = p[2];
-                    if (xx + 3 < a.W) f.w = p[3];
+                    if (xx + 0 < a.Wo) f.x = p[0];
+                    if (xx + 1 < a.Wo) f.y = p[1];
+                    if (xx + 2 < a.Wo) f.z = p[2];
+                    if (xx + 3 < a.Wo) f.w = p[3];
                 }
             }
             uint2 w;
@@ -332,11 +334,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
         }
         // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU): item = (patch pixel, channel half) ----
-        for (int w = tid; w < 2 * WNPIX; w += NT) {
-            const int half = w >= WNPIX ? 1 : 0;
-            const int pix = w - half * WNPIX;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        for (int w = tid; w < 2 * NPIXk; w += NT) {
+            const int half = w >= NPIXk ? 1 : 0;
+            const int pix = w - half * NPIXk;
+            const int py = pix / PWk, px = pix - py * PWk;
+            const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
             const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const int cb = c0 + half * 16;
             const float* p = xb + (long)cb * HW + (long)iy * a.W + ix;
@@ -368,14 +370,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 #pragma unroll 2
         for (int s = 0; s < 8; ++s) {
             const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(dys + (wave * 32 + r) * DYLD + 16 * s + 8 * h);
-            const int prow = s >> 1, pcol = (s & 1) * 16 + 8 * h + tq;   // tile-local pixel of this lane's block row
+            const int prow = s >> 1, pcol = (s & 1) * 16 + 8 * h + tq;   // tile-local OUTPUT pixel of this lane's block row
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const unsigned short* p0 = patch + ((prow + ky) * PW + pcol + kx) * LD + 16 * tg + 4 * tp;
-                    const s16x4_t lo = lds_tr_read(p0);            // pixels +0..3
-                    const s16x4_t hi = lds_tr_read(p0 + 4 * LD);   // pixels +4..7
+                    const unsigned short* p0 = patch + ((prow * S + ky) * PWk + pcol * S + kx) * LD + 16 * tg + 4 * tp;
+                    const s16x4_t lo = lds_tr_read(p0);                // output pixels +0..3
+                    const s16x4_t hi = lds_tr_read(p0 + 4 * S * LD);   // output pixels +4..7
                     const bf16x8_t fb = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_native_t, fa), __builtin_bit_cast(bf16x8_native_t, fb),
@@ -402,10 +404,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
 // dw (Cout, Cin, 3, 3) fp32 is overwritten.  Same input-transform contract as gd_conv2d.
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, const float* in_scale,
-                                const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, float* dw,
-                                void* stream) {
+                                const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, int stride,
+                                float* dw, void* stream) {
     GD_CHECK_ARG(dy && x && dw, "gd_conv3x3_wgrad: null pointer");
-    GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0, "gd_conv3x3_wgrad: bad sizes");
+    GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gd_conv3x3_wgrad: bad sizes");
     GD_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gd_conv3x3_wgrad: in_scale/in_shift must come together");
     hipStream_t s = (hipStream_t)stream;
     GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) == hipSuccess, "gd_conv3x3_wgrad: memset failed");
@@ -413,8 +415,9 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, lon
     a.dy = dy; a.dy_bs = dy_bs; a.x = x; a.x_bs = x_bs;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.dw = dw; a.B = B; a.M = Cout; a.Ck = Cin; a.H = H; a.W = W;
-    a.tiles_x = (W + TW - 1) / TW;
-    a.tiles_y = (H + WTH - 1) / WTH;
+    a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;     // 3x3, pad 1
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    a.tiles_y = (a.Ho + WTH - 1) / WTH;
     const long ntiles = (long)B * a.tiles_x * a.tiles_y;
     GD_CHECK_ARG(ntiles < (1L << 31), "gd_conv3x3_wgrad: too many tiles");
     // m-tiles per workgroup: 2, 4 or 6 waves, whichever pads Cout least (ties -> the larger block).  A 1-wave
@@ -434,9 +437,15 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, lon
     a.tiles_per_split = (int)((ntiles + splits - 1) / splits);
     splits = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     dim3 grid(chunks, mblocks, (unsigned)splits);
-    if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2>), grid, dim3(128), 0, s, a);
-    else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6>), grid, dim3(384), 0, s, a);
+    if (stride == 1) {
+        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1>), grid, dim3(128), 0, s, a);
+        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 1>), grid, dim3(384), 0, s, a);
+    } else {
+        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 2>), grid, dim3(128), 0, s, a);
+        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 2>), grid, dim3(384), 0, s, a);
+    }
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -202,9 +202,9 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
     B, Cout, Ho, Wo = dy.shape
     _, Cin, Hi, Wi = x.shape
     dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
-    if USE_CONV3X3_FAST and k == 3 and stride == 1 and pad == 1 and precision == L.PREC_BF16:
+    if USE_CONV3X3_FAST and k == 3 and stride in (1, 2) and pad == 1 and precision == L.PREC_BF16:
         L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift), int(in_relu), B,
-                                       Cout, Cin, Hi, Wi, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+                                       Cout, Cin, Hi, Wi, stride, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
         return dw
     if k == 1 and stride == 1 and pad == 0 and in_scale is None:
         # 1x1: dW = dY X^T with both operands pixel-contiguous -> plain NT GEMM (float4-staged when aligned)

@@ -88,8 +88,8 @@ int gd_conv3x3(const gd_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
 /* weight gradient of the same convolution (bf16 MFMA, fp32 atomics across the pixel splits):
  * dw (Cout, Cin, 3, 3) = sum_{b,p} dy[b][co][p] * relu?(x*in_scale + in_shift)[b][ci][p (+) tap]; dw is overwritten. */
 int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, const float* in_scale,
-                     const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, float* dw,
-                     void* stream);
+                     const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, int stride, float* dw,
+                     void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
 
 /* ------------------------------------------------------------------------------------------
  * "NT" GEMM with the long reduction split over workgroups:

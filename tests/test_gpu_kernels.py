@@ -314,6 +314,35 @@ def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
     assert_close(outs[True][2], dwr, BF16_TOL, "patch wgrad vs oracle", rell2)
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 64, 96, 64), (2, 64, 32, 64, 128), (1, 128, 17, 35, 256), (1, 40, 9, 130, 24)])
+def test_conv3x3_stride2_patch_kernel(gd, shape):
+    """the discriminator's stride-2 3x3 convs (discriminator.py:11-26): LDS-patch forward and weight gradient
+    against the generic kernels (same bf16 operands) and the oracle; odd sizes exercise the ragged tiles."""
+    ops, K = _ops()
+    from gan_danet_amd import _lib as L
+    B, Cin, H, W, Cout = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = bf16_round(seeded((B, Cin, H, W), 81)).to(DEV)
+    w = bf16_round(seeded((Cout, Cin, 3, 3), 82, 1.0 / math.sqrt(Cin * 9))).to(DEV)
+    bias = seeded((Cout,), 83, 0.1).to(DEV)
+    dy = bf16_round(seeded((B, Cout, Ho, Wo), 84)).to(DEV)
+    outs = {}
+    for fast in (True, False):
+        K.USE_CONV3X3_FAST = fast
+        try:
+            y = K.conv2d_fwd(x, w, bias, 2, 1, L.PREC_BF16, act=ops.ACT_LEAKY)
+            dw = K.conv2d_wgrad(dy, x, 3, 2, 1, L.PREC_BF16)
+        finally:
+            K.USE_CONV3X3_FAST = True
+        outs[fast] = (y, dw)
+    assert_close(outs[True][0], outs[False][0].cpu(), 1e-5, "stride-2 patch vs generic fwd")
+    assert_close(outs[True][1], outs[False][1].cpu(), 1e-4, "stride-2 patch vs generic wgrad")
+    yr = F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), bias.cpu(), stride=2, padding=1), 0.2)
+    assert_close(outs[True][0], yr, BF16_TOL, "stride-2 fwd vs oracle")
+    dwr = torch.nn.grad.conv2d_weight(x.cpu(), (Cout, Cin, 3, 3), dy.cpu(), stride=2, padding=1)
+    assert_close(outs[True][1], dwr, BF16_TOL, "stride-2 wgrad vs oracle", rell2)
+
+
 @pytest.mark.parametrize("shape", [(2, 184, 16, 16, 184), (1, 88, 8, 12, 44), (2, 520, 8, 8, 64), (1, 32, 5, 7, 24)])
 def test_conv1x1_transpose_read_kernel(gd, shape):
     """1x1 convs (projections, transitions, channel_adjust): transpose-read kernel with and without the fused
