@@ -91,10 +91,10 @@ SIGNATURES = {
     "gd_tv": (_i, [_p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "gd_ssim": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "gd_adamw": (_i, [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f, _p]),
-    "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
-    "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
+    "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
-    "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _i, _p, _i, _i, _i, _p]),
+    "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
 }
 
 _lib = None

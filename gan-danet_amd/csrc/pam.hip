@@ -5,7 +5,11 @@
 //
 // The N x N matrices are never materialised.  d is zero-padded to 32, C to a multiple of 32 (Cp).
 //
-// Forward: one workgroup = 4 waves = 128 queries (32 per wave), K/V streamed in 64-key tiles through LDS.
+// Operand contract: q is packed PRE-SCALED by log2(e) (gd_pack_bf16 scale_imm), so every S tile comes out of the
+//   MFMA in the log2 domain, and the softmax shift (running max in the forward, log-sum-exp in the backward) and
+//   the backward's row term delta are fed in as the MFMA's accumulator input: exp2 is applied to the accumulator
+//   as it stands, no per-element multiply / subtract is left on the VALU.
+// Forward: one workgroup = 8 waves = 256 queries (32 per wave), K/V streamed in 128-key tiles through LDS.
 //   S^T = K Q^T is computed with the KEY index on the accumulator rows and the QUERY on the lane, so
 //   * the row softmax is lane-local (+ one cross-half shuffle),
 //   * the probability tile is already the B operand of O^T = V P^T  (accumulator-as-operand, no LDS trip),
@@ -45,180 +49,10 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int s) {
     return __builtin_bit_cast(bf16x8_t, w);
 }
 
-// A/B fragment whose k runs over an accumulator-row-ordered index stored contiguously in an LDS row:
-// elements [base + 4h .. +3] and [base + 8 + 4h .. +3]  (two 8-byte reads)
-__device__ __forceinline__ bf16x8_t read_perm_frag(const unsigned short* row, int base, int h) {
-    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(row + base + 4 * h);
-    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(row + base + 8 + 4 * h);
-    const u32x4_t w = {lo.x, lo.y, hi.x, hi.y};
-    return __builtin_bit_cast(bf16x8_t, w);
-}
-
 // =====================================================================================================
 // forward
 // =====================================================================================================
-constexpr int F_KT = 64;    // keys per tile
 constexpr int F_KLD = 40;   // K row: 32 d + 8 pad (80 B) -> conflict-free 16-B fragment reads
-constexpr int F_VLD = 72;   // V row: 64 keys + 8 pad (144 B) -> conflict-free 16-B fragment reads (keys perm16-ordered)
-
-template <int CT>
-__global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* __restrict__ qt,
-                                                        const unsigned short* __restrict__ kt,
-                                                        const unsigned short* __restrict__ v, int N, int Npad, int C,
-                                                        const float* __restrict__ gamma, const float* __restrict__ x,
-                                                        long x_bs, float* __restrict__ out, long out_bs,
-                                                        float* __restrict__ o_attn, float* __restrict__ lse) {
-    constexpr int CP = CT * 32;
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[F_KT * F_KLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[CP * F_VLD];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-
-    const unsigned short* ktb = kt + (long)b * Npad * 32;
-    const unsigned short* vb = v + (long)b * CP * Npad;
-
-    // Q as the B operand of S^T = K Q^T: lane holds Q[query r][d = 16s + 8h + j]
-    bf16x8_t qf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
-
-    f32x16_t o[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
-    float m = -1e30f, l = 0.f;  // running max (log2 domain) and sum of this lane's query
-
-    const int nkt = (N + F_KT - 1) / F_KT;
-
-    // staging registers: K tile = 256 x 16 B; V tile = CP*8 chunks of 16 B = CT per thread
-    u32x4_t kreg;
-    u32x4_t vreg[CT];
-    const int k_key = tid >> 2, k_chunk = tid & 3;
-    auto load_tile = [&](int t) {
-        const int k0 = t * F_KT;
-        kreg = *reinterpret_cast<const u32x4_t*>(ktb + (long)(k0 + k_key) * 32 + k_chunk * 8);
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int idx = tid + i * 256;
-            const int c = idx >> 3, qd = idx & 7;
-            vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (long)c * Npad + k0 + qd * 8);
-        }
-    };
-    auto store_tile = [&]() {
-        *reinterpret_cast<u32x4_t*>(Ks + k_key * F_KLD + k_chunk * 8) = kreg;
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int idx = tid + i * 256;
-            const int c = idx >> 3, qd = idx & 7;
-            *reinterpret_cast<u32x4_t*>(Vs + c * F_VLD + qd * 8) = vreg[i];   // 144-B rows: 16-byte aligned
-        }
-    };
-
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-
-    for (int t = 0; t < nkt; ++t) {
-        if (t + 1 < nkt) load_tile(t + 1);
-
-        // ---- S^T tiles (keys on rows, query on the lane) ----
-        f32x16_t sacc[2];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[sub][e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8_t kf =
-                    *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
-                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
-            }
-        }
-        // ---- online softmax (log2 domain): m, l track max and sum of s*log2(e) ----
-        if ((t + 1) * F_KT > N) {   // wave-uniform: only the last tile masks padded keys
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if ((t * F_KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
-        }
-        float mloc = sacc[0][0];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
-        const float m_new = fmaxf(m, mloc);
-        if (__any(m_new > m)) {  // wave-uniform: skip the O rescale when no query's max moved
-            const float alpha = gd_exp2_fast(m - m_new);
-            l *= alpha;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
-            m = m_new;
-        }
-        float lsum = 0.f;
-        const float neg_m = -m;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
-                sacc[sub][e] = p;
-                lsum += p;
-            }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l += lsum;
-
-        // ---- O^T += V P^T : A = V rows (channel), k = keys in accumulator-row order; B = P fragments ----
-        bf16x8_t pf[2][2];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const unsigned short* vrow = Vs + (ct * 32 + r) * F_VLD;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + sub * 32 + s * 16 + 8 * h);
-                    o[ct] = mfma_bf16(vf, pf[sub][s], o[ct]);
-                }
-        }
-        __syncthreads();
-        if (t + 1 < nkt) {
-            store_tile();
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: O / l, residual, log-sum-exp ----
-    const int qi = q0 + r;
-    if (qi < N) {
-        const float inv_l = 1.f / l;
-        const float g = *gamma;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = ct * 32 + acc_row(e, h);
-                if (c < C) {
-                    const float val = o[ct][e] * inv_l;
-                    o_attn[((long)b * C + c) * N + qi] = val;
-                    out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
-                }
-            }
-        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
-    }
-}
 
 // =====================================================================================================
 // forward, LDS-DMA variant: K/V tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers,
@@ -227,12 +61,12 @@ __global__ __launch_bounds__(256, 2) void pam_fwd_kernel(const unsigned short* _
 // chunks + 1 pad) / nine (V rows: 8 + 1) fetch a duplicate chunk into the pad slot.
 // =====================================================================================================
 constexpr int D_KROWCH = 5;                 // 16-byte chunks per K row (80 B)
-constexpr int D_VROWCH = 9;                 // 16-byte chunks per V row (144 B)
-constexpr int D_VLD = D_VROWCH * 8;         // 72 elements
 
 // NW waves = NW*32 queries per workgroup share each staged K/V tile (8 waves: half the L2 -> LDS streaming per query)
 // KT keys per staged tile (64 or 128: fewer barriers and DMA issue rounds per key, more independent work per wave)
-template <int CT, int NW, int KT = 64>
+// ONES: the packed V carries a row of ones in its last padded channel (Cp - 1), so the softmax denominator is
+// accumulated by the same MFMAs as O (it is row 31 of the last channel tile) instead of 1 VALU add per element
+template <int CT, int NW, int KT, bool ONES>
 __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned short* __restrict__ qt,
                                                             const unsigned short* __restrict__ kt,
                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
@@ -262,32 +96,34 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     for (int s = 0; s < 2; ++s)
         qf[s] = *reinterpret_cast<const bf16x8_t*>(qt + ((long)b * Npad + q0 + r) * 32 + s * 16 + 8 * h);
 
-    // ---- DMA plan of this lane: source of its chunk in tile 0 and elements to advance per tile ----
-    const unsigned short* src[PPW];
-    int adv[PPW];
-    bool live[PPW];
+    // ---- DMA plan of this lane: 32-bit byte offset of its chunk inside the tile's K / V source.  Pieces never
+    // straddle K and V (KCH is a multiple of 64), so the 64-bit base of a piece is wave-uniform (SGPRs) and only
+    // these offsets live in VGPRs across the loop ----
+    static_assert(KCH % 64 == 0, "a DMA piece must be all-K or all-V");
+    unsigned int voff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int piece = wave + NW * i;
         const int c = piece * 64 + lane;
-        live[i] = piece < NPIECE && c < NCH;
-        if (c < KCH) {
+        if (piece * 64 < KCH) {
             const int row = c / D_KROWCH, part = c - row * D_KROWCH;
-            src[i] = ktb + (long)row * 32 + (part < 4 ? part : 3) * 8;
-            adv[i] = KT * 32;
+            voff[i] = (unsigned int)(row * 32 + (part < 4 ? part : 3) * 8) * 2u;
         } else {
             const int c2 = (c < NCH ? c : NCH - 1) - KCH;
             const int row = c2 / VROWCH, part = c2 - row * VROWCH;
-            src[i] = vb + (long)row * Npad + (part < KT / 8 ? part : KT / 8 - 1) * 8;
-            adv[i] = KT;
+            voff[i] = ((unsigned int)row * (unsigned int)Npad + (unsigned int)(part < KT / 8 ? part : KT / 8 - 1) * 8u) * 2u;
         }
     }
     auto dma_tile = [&](int t, int slot) {
+        const char* kbase = reinterpret_cast<const char*>(ktb + (long)t * (KT * 32));
+        const char* vbase = reinterpret_cast<const char*>(vb + (long)t * KT);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            if (live[i]) {
-                unsigned short* dst = ring + slot * TILE + (wave + NW * i) * 512;   // wave-uniform piece base
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long)t * adv[i]),
+            const int piece = wave + NW * i;
+            if (piece < NPIECE && piece * 64 + lane < NCH) {
+                unsigned short* dst = ring + slot * TILE + piece * 512;   // wave-uniform piece base
+                const char* base = piece * 64 < KCH ? kbase : vbase;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[i]),
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
         }
@@ -298,7 +134,12 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
-    float m = -1e30f, l = 0.f;
+    // m: running row maximum (log2 domain; q arrives pre-scaled by log2 e), kept bf16-representable and fed to the
+    // S MFMAs through the spare k-slot d = 31: k carries 1.0 there (gd_pack_bf16 ones_row) and this wave's Q
+    // fragment carries -m, so a tile comes out of the matrix pipe as s - m with zero-initialised accumulators and
+    // no per-score subtract.  Only a tile that RAISES the maximum (wave-uniform test) pays a shift and the O
+    // rescale; tile 0 always does and thereby sets m.
+    float m = 0.f, l = 0.f;
     const int nkt = (N + KT - 1) / KT;
 
     dma_tile(0, 0);
@@ -334,35 +175,52 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
         for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * LOG2E;
-        const float m_new = fmaxf(m, mloc);
-        if (__any(m_new > m)) {
-            const float alpha = gd_exp2_fast(m - m_new);
-            l *= alpha;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
-            m = m_new;
-        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         float lsum = 0.f;
-        const float neg_m = -m;
+        bf16x8_t pf[NSUB][2];     // P^T tile as the B operand of O^T += V P^T (accumulator-as-operand)
+        if (t == 0 || __any(mloc > 0.f)) {
+            // new maximum, rounded UP to bf16 so that it survives the trip through the Q fragment exactly
+            const float want = m + (t == 0 ? mloc : fmaxf(mloc, 0.f));
+            const unsigned int wb = __builtin_bit_cast(unsigned int, want);
+            const float m_new = __builtin_bit_cast(float, want > 0.f ? (wb + 0xFFFFu) & 0xFFFF0000u : wb & 0xFFFF0000u);
+            const float shift = m_new - m;
+            if (t != 0) {
+                const float alpha = gd_exp2_fast(-shift);
+                l *= alpha;
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = gd_exp2_fast(fmaf(sacc[sub][e], LOG2E, neg_m));
-                sacc[sub][e] = p;
-                lsum += p;
+                    for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
             }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l += lsum;
+            m = m_new;
+            if (h) qf[1][7] = (short)(__builtin_bit_cast(unsigned int, -m_new) >> 16);   // d = 31 lives in lane half 1
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sacc[sub][e] = gd_exp2_fast(sacc[sub][e] - shift);
+                    if (!ONES) lsum += sacc[sub][e];
+                }
+                pf[sub][0] = pack_frag(sacc[sub], 0);
+                pf[sub][1] = pack_frag(sacc[sub], 1);
+            }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sacc[sub][e] = gd_exp2_fast(sacc[sub][e]);
+                    if (!ONES) lsum += sacc[sub][e];
+                }
+                pf[sub][0] = pack_frag(sacc[sub], 0);
+                pf[sub][1] = pack_frag(sacc[sub], 1);
+            }
+        }
+        if (!ONES) {
+            lsum += __shfl_xor(lsum, 32, 64);
+            l += lsum;
+        }
 
-        bf16x8_t pf[NSUB][2];
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) pf[sub][s] = pack_frag(sacc[sub], s);
         // V fragments are read in batches of FB ahead of the MFMAs that consume them (the scheduler is pinned with
         // sched_group_barrier: FB LDS reads, then FB MFMAs), so one LDS round trip is paid per batch, not per MFMA
         constexpr int FB = 8, NF = 2 * NSUB * CT;
@@ -390,6 +248,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
         }
     }
 
+    if (ONES) l = __shfl(o[CT - 1][15], r + 32, 64);   // channel Cp-1 = accumulator row 31: register 15 of lane half 1
     const int qi = q0 + r;
     if (qi < N) {
         const float inv_l = 1.f / l;
@@ -405,198 +264,11 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                     out[(long)b * out_bs + (long)c * N + qi] = fmaf(g, val, x[(long)b * x_bs + (long)c * N + qi]);
                 }
             }
-        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;
+        if (h == 0) lse[(long)b * N + qi] = (m + log2f(l)) * LN2;   // natural-log LSE of the UNSCALED energies
     }
 }
 
-// =====================================================================================================
-// backward, part 1: dK^T and dV^T  (key-parallel; a workgroup owns NW*32 keys and sweeps the queries)
-// =====================================================================================================
 constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
-constexpr int B_TLD = 36;   // transposed tiles rows [..][32 i] (72 B): 8-B reads, conflict free
-
-// VLDS = true keeps this workgroup's V rows in LDS instead of 8*CT registers per lane (Cp = 192 would not fit 256)
-template <int CT, int NW, bool VLDS = false>
-__global__ __launch_bounds__(NW * 64, NW / 4) void pam_bwd_dkv_kernel(
-    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ qn,
-    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const unsigned short* __restrict__ don,
-    const float* __restrict__ lse, const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn,
-    float* __restrict__ dv) {
-    constexpr int CP = CT * 32;
-    constexpr int NT = NW * 64;
-    constexpr int DLD = CP + 8;                    // dO tile rows [i][CP c] (+16 B): 16-B reads conflict free
-    constexpr int NCHUNK = 256 + 256 * CT;         // 16-byte chunks staged per query tile
-    constexpr int NPRE = (NCHUNK + NT - 1) / NT;   // chunks per thread
-    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
-    __shared__ __attribute__((aligned(16))) unsigned short QTs[32 * B_TLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOTs[CP * B_TLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vls[VLDS ? NW * 32 * DLD : 8];   // V rows [key][CP c]
-    __shared__ float Ls[32], Ds[32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int j0 = blockIdx.x * (NW * 32) + wave * 32;  // this wave's 32 keys
-    const long nb = (long)b * Npad;
-
-    // ---- persistent per-wave operands: K (B operand of S = Q K^T), V (B operand of dP = dO V^T) ----
-    bf16x8_t kfB[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
-    bf16x8_t vfB[VLDS ? 1 : 2 * CT];
-    if constexpr (VLDS) {
-        // the workgroup's NW*32 keys x CP channels, once: 16-byte chunks, rows padded to DLD (conflict-free reads)
-        const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * (NW * 32)) * CP;
-        for (int c = tid; c < NW * 32 * (CP / 8); c += NT) {
-            const int row = c / (CP / 8), ch = c - row * (CP / 8);
-            *reinterpret_cast<u32x4_t*>(Vls + row * DLD + ch * 8) =
-                *reinterpret_cast<const u32x4_t*>(vsrc + (long)row * CP + ch * 8);
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 2 * CT; ++s)
-            vfB[s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + r) * CP + s * 16 + 8 * h);
-    }
-
-    f32x16_t dvacc[CT], dkacc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dkacc[e] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
-
-    const bool key_ok = (j0 + r) < N;
-    const bool need_mask = (int)(blockIdx.x + 1) * (NW * 32) > N;   // uniform over the workgroup
-    const int nqt = (N + 31) / 32;
-
-    // ---- staging: global -> registers (prefetch, issued before the MFMAs of the previous tile) -> LDS ----
-    u32x4_t pre[NPRE];
-    float pre_s = 0.f;
-    auto load_tile = [&](int qtile) {
-        const int i0 = qtile * 32;
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int c = tid + k * NT;
-            if (c < 128) {                                   // Q rows [i][32 d]
-                pre[k] = *reinterpret_cast<const u32x4_t*>(qt + (nb + i0 + (c >> 2)) * 32 + (c & 3) * 8);
-            } else if (c < 256) {                            // Q^T rows [d][32 i]
-                const int c2 = c - 128;
-                pre[k] = *reinterpret_cast<const u32x4_t*>(qn + ((long)b * 32 + (c2 >> 2)) * Npad + i0 + (c2 & 3) * 8);
-            } else if (c < 256 + 128 * CT) {                 // dO rows [i][CP c]
-                const int c2 = c - 256;
-                const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
-                pre[k] = *reinterpret_cast<const u32x4_t*>(dot_ + (nb + i0 + i) * CP + ch * 8);
-            } else if (c < NCHUNK) {                         // dO^T rows [c][32 i]
-                const int c2 = c - 256 - 128 * CT;
-                pre[k] = *reinterpret_cast<const u32x4_t*>(don + ((long)b * CP + (c2 >> 2)) * Npad + i0 + (c2 & 3) * 8);
-            }
-        }
-        if (tid < 64) {
-            const int i = i0 + (tid & 31);
-            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;   // negated once here
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int c = tid + k * NT;
-            if (c < 128) {
-                *reinterpret_cast<u32x4_t*>(Qs + (c >> 2) * B_QLD + (c & 3) * 8) = pre[k];
-            } else if (c < 256) {
-                const int c2 = c - 128;
-                u32x2_t* dst = reinterpret_cast<u32x2_t*>(QTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8);
-                dst[0] = u32x2_t{pre[k].x, pre[k].y};
-                dst[1] = u32x2_t{pre[k].z, pre[k].w};
-            } else if (c < 256 + 128 * CT) {
-                const int c2 = c - 256;
-                const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
-                *reinterpret_cast<u32x4_t*>(dOs + i * DLD + ch * 8) = pre[k];
-            } else if (c < NCHUNK) {
-                const int c2 = c - 256 - 128 * CT;
-                u32x2_t* dst = reinterpret_cast<u32x2_t*>(dOTs + (c2 >> 2) * B_TLD + (c2 & 3) * 8);
-                dst[0] = u32x2_t{pre[k].x, pre[k].y};
-                dst[1] = u32x2_t{pre[k].z, pre[k].w};
-            }
-        }
-        if (tid < 32) Ls[tid] = pre_s;
-        else if (tid < 64) Ds[tid - 32] = pre_s;
-    };
-
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-
-    for (int qtile = 0; qtile < nqt; ++qtile) {
-        const int i0 = qtile * 32;
-        if (qtile + 1 < nqt) load_tile(qtile + 1);
-
-        // ---- S' = Q K^T - lse (rows i, lane j) and dP - delta = dO V^T - delta -----------------------------
-        f32x16_t sacc, dpacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            sacc[e] = Ls[acc_row(e, h)];    // -lse   (row constants as initial accumulators)
-            dpacc[e] = Ds[acc_row(e, h)];   // -delta
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(Qs + r * B_QLD + s * 16 + 8 * h);
-            sacc = mfma_bf16(qa, kfB[s], sacc);
-        }
-#pragma unroll
-        for (int s = 0; s < 2 * CT; ++s) {
-            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
-            if constexpr (VLDS) {
-                const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vls + (wave * 32 + r) * DLD + s * 16 + 8 * h);
-                dpacc = mfma_bf16(da, vb, dpacc);
-            } else {
-                dpacc = mfma_bf16(da, vfB[s], dpacc);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
-        if (need_mask || i0 + 32 > N) {   // workgroup-uniform: padded keys in this block, or the ragged last query tile
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (!(key_ok && (i0 + acc_row(e, h)) < N)) sacc[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dpacc[e] *= sacc[e];   // dS = P (dP - delta)
-        bf16x8_t pf[2], dsf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            pf[s] = pack_frag(sacc, s);
-            dsf[s] = pack_frag(dpacc, s);
-        }
-        // ---- dV^T[c][j] += dO^T[c][i] P[i][j] ;  dK^T[d][j] += Q^T[d][i] dS[i][j] ---------------------------
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const unsigned short* row = dOTs + (ct * 32 + r) * B_TLD;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_perm_frag(row, s * 16, h), pf[s], dvacc[ct]);
-        }
-        {
-            const unsigned short* row = QTs + r * B_TLD;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) dkacc = mfma_bf16(read_perm_frag(row, s * 16, h), dsf[s], dkacc);
-        }
-        __syncthreads();  // everyone is done reading this tile
-        if (qtile + 1 < nqt) {
-            store_tile();
-            __syncthreads();
-        }
-    }
-
-    // ---- write dV^T (channel-major, coalesced along keys) and dK^T ----------------------------------------
-    const int j = j0 + r;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
-}
 
 // =====================================================================================================
 // backward, part 1c: dK^T / dV^T, transpose-read variant.  Only Q [i][d] and dO [i][c] are staged per query
@@ -695,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
             pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
         if (tid < 64) {
             const int i = qtile * 32 + (tid & 31);
-            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] : delta[(long)b * N + i]) : 0.f;
+            pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] * LOG2E : delta[(long)b * N + i]) : 0.f;
         }
     };
     auto store_tile = [&]() {
@@ -732,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
             dpacc = mfma_bf16(da, vb, dpacc);
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e] * LOG2E);   // P
+        for (int e = 0; e < 16; ++e) sacc[e] = gd_exp2_fast(sacc[e]);   // P (q pre-scaled, -lse*log2e was the accumulator input)
         if (need_mask || i0 + 32 > N) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
@@ -765,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e];
+    for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e] * LN2;   // Q^T was q * log2 e
 }
 
 // =====================================================================================================
@@ -865,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
             f32x16_t sacc, dpacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                sacc[e] = 0.f;
+                sacc[e] = nlse;
                 dpacc[e] = ndelta;
             }
 #pragma unroll
@@ -890,8 +562,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = gd_exp2_fast(fmaf(sacc[e], LOG2E, nlse));
-                dpacc[e] = p * dpacc[e];  // dS^T
+                dpacc[e] = gd_exp2_fast(sacc[e]) * dpacc[e];  // dS^T = P (dP - delta)
             }
             if (tail) {   // wave-uniform: padded keys of the last tile contribute nothing
 #pragma unroll
@@ -922,68 +593,42 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
     }
 
 extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
-                                const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn,
-                                float* lse, void* stream) {
+                                int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
+                                float* o_attn, float* lse, void* stream) {
     GD_CHECK_ARG(qt && kt && v && gamma && x && out && o_attn && lse, "gd_pam_flash_fwd: null pointer");
-    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 128 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 128 >= N");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
-    dim3 grid(Npad / 128, B);
-    // default 16: LDS-DMA ring, 8 waves (256 queries) per workgroup, 128-key tiles; 8 / 1: 64-key tiles with 8 / 4
-    // waves; 0: register-staged 4-wave kernel.  Measured at B=4, N=65536, C=184: 7.72 / 7.82 / 8.43 / 8.75 ms.
-    static const int dma_env = getenv("GD_PAM_FWD_DMA") ? atoi(getenv("GD_PAM_FWD_DMA")) : 16;
-    if (dma_env == 16 && Npad % 256 == 0) {  // 8 waves, 128-key tiles
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0,
-                                                     (hipStream_t)stream, (const unsigned short*)qt,
-                                                     (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C,
-                                                     gamma, x, x_bs, out, out_bs, o_attn, lse));
-    } else if (dma_env == 8 && Npad % 256 == 0) {   // 8 waves = 256 queries per workgroup
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0,
-                                                     (hipStream_t)stream, (const unsigned short*)qt,
-                                                     (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C,
-                                                     gamma, x, x_bs, out, out_bs, o_attn, lse));
-    } else if (dma_env) {   // default: LDS-DMA ring (no staging registers, one barrier per key tile)
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 4>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                     (const unsigned short*)qt, (const unsigned short*)kt,
-                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
-                                                     o_attn, lse));
-    } else {         // GD_PAM_FWD_DMA=0: register-staged variant (A/B reference)
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_kernel<CT>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                     (const unsigned short*)qt, (const unsigned short*)kt,
-                                                     (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs,
-                                                     o_attn, lse));
+    GD_CHECK_ARG(!v_ones || C < Cp, "gd_pam_flash_fwd: v_ones needs a spare padded channel (C < Cp)");
+    // LDS-DMA ring, 8 waves (256 queries) per workgroup, 128-key tiles.  Rejected after measurement (B=4, N=65536,
+    // C=184, this kernel 7.23 ms): 64-key tiles with 8 / 4 waves (+1 % / +9 %), register-staged 4-wave kernel
+    // (+13 %), 4 waves x 64 queries with O in the accumulation registers (inline-asm MFMA; halves the LDS reads
+    // per MFMA but leaves one wave per SIMD with nothing to overlap its softmax: +39 %).  Halving the V fragment
+    // reads of THIS kernel (experiment, wrong numerics) changed nothing: it is not LDS-bandwidth bound.
+    const dim3 grid(Npad / 256, B), block(512);
+    hipStream_t s = (hipStream_t)stream;
+#define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse
+    if (v_ones) {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true>), grid, block, 0, s, PAM_FWD_ARGS));
+    } else {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, false>), grid, block, 0, s, PAM_FWD_ARGS));
     }
+#undef PAM_FWD_ARGS
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
-                                const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
-                                int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream) {
+extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
+                                const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn,
+                                float* dkn, float* dv, void* stream) {
     GD_CHECK_ARG(qt && kt && kn && vt && dot_ && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
     hipStream_t s = (hipStream_t)stream;
-    // 8 waves (2 per SIMD, 256 keys per workgroup) while the accumulators fit 256 registers; Cp = 192 needs the
-    // whole 512-register file: 4 waves, one per SIMD, 128 keys per workgroup
-    static const int v3_env = getenv("GD_PAM_DKV_V3") ? atoi(getenv("GD_PAM_DKV_V3")) : 1;
-    GD_CHECK_ARG(v3_env || (qn && don), "gd_pam_flash_bwd: qn/don are required by the GD_PAM_DKV_V3=0 dK/dV variant");
-    if (v3_env) {                   // default: transpose-read variant, 4 waves, two independent workgroups per CU
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
-                                                     (const unsigned short*)qt, (const unsigned short*)kt,
-                                                     (const unsigned short*)vt, (const unsigned short*)dot_, lse, delta,
-                                                     N, Npad, dkn, dv));
-    } else if (Cp == 192) {         // A/B reference: 8-wave kernel staging q^T / dO^T copies; V rows in LDS at Cp = 192
-        hipLaunchKernelGGL((pam_bwd_dkv_kernel<6, 8, true>), dim3(Npad / 256, B), dim3(512), 0, s,
-                           (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)qn,
-                           (const unsigned short*)vt, (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
-                           N, Npad, dkn, dv);
-    } else {
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv_kernel<CT, 8>), dim3(Npad / 256, B), dim3(512), 0, s,
-                                                     (const unsigned short*)qt, (const unsigned short*)kt,
-                                                     (const unsigned short*)qn, (const unsigned short*)vt,
-                                                     (const unsigned short*)dot_, (const unsigned short*)don, lse, delta,
-                                                     N, Npad, dkn, dv));
-    }
+    // dK / dV: transpose-read kernel, 4 waves (128 keys), two independent workgroups per CU
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
+                                                 (const unsigned short*)qt, (const unsigned short*)kt,
+                                                 (const unsigned short*)vt, (const unsigned short*)dot_, lse, delta, N,
+                                                 Npad, dkn, dv));
     // dQ: 8 waves (256 queries) per workgroup, 128-key LDS-DMA tiles; kn must be packed perm16 along the keys
     PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0, s,
                                                  (const unsigned short*)qt, (const unsigned short*)kt,

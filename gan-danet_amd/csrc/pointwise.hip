@@ -151,18 +151,19 @@ __global__ void add_transpose_kernel(const float* __restrict__ a, float* __restr
 
 // fp32 (R, Cc) plane -> bf16 plain copy (zero padded to Rp x ldp) and/or bf16 transpose (zero padded Ccp x ldt)
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ s, long s_bs, int R, int Cc,
-                                                       const float* __restrict__ scale, unsigned short* __restrict__ plain,
-                                                       int Rp, int ldp, unsigned short* __restrict__ tr, int Ccp, int ldt,
-                                                       int perm16) {
+                                                       const float* __restrict__ scale, float scale_imm,
+                                                       unsigned short* __restrict__ plain, int Rp, int ldp,
+                                                       unsigned short* __restrict__ tr, int Ccp, int ldt, int perm16,
+                                                       int ones_row) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const float* sp = s + (long)b * s_bs;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float k = scale ? *scale : 1.f;
+    const float k = scale ? scale_imm * (*scale) : scale_imm;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        const float v = (r < R && c < Cc) ? k * sp[(long)r * Cc + c] : 0.f;
+        const float v = r == ones_row ? 1.f : (r < R && c < Cc) ? k * sp[(long)r * Cc + c] : 0.f;
         tile[i][tx] = v;
         if (plain && r < Rp && c < ldp) {
             // perm16: inside every group of 16 columns store [0-3, 8-11, 4-7, 12-15], the order in which a lane half
@@ -389,19 +390,22 @@ extern "C" int gd_add_transpose(const float* a, float* out, int B, int n, void* 
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, void* plain,
-                            int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, void* stream) {
+extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm,
+                            void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16,
+                            int ones_row, void* stream) {
     GD_CHECK_ARG(s && (plain || transposed) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_bf16: bad arguments");
     GD_CHECK_ARG(!plain || (Rp_plain >= R && ld_plain >= Cc), "gd_pack_bf16: plain padding smaller than the data");
     GD_CHECK_ARG(!perm16 || (plain && ld_plain % 16 == 0), "gd_pack_bf16: perm16 needs a plain output with ld % 16 == 0");
     GD_CHECK_ARG(!transposed || (Ccp_t >= Cc && ld_t >= R), "gd_pack_bf16: transposed padding smaller than the data");
+    GD_CHECK_ARG(ones_row < 0 || (ones_row >= R && (!plain || ones_row < Rp_plain) && (!transposed || ones_row < ld_t)),
+                 "gd_pack_bf16: ones_row must be a padding row");
     int rows = R, cols = Cc;
     if (plain) { rows = rows > Rp_plain ? rows : Rp_plain; cols = cols > ld_plain ? cols : ld_plain; }
     if (transposed) { rows = rows > ld_t ? rows : ld_t; cols = cols > Ccp_t ? cols : Ccp_t; }
     GD_CHECK_ARG(gd_cdiv(rows, 32) <= 65535, "gd_pack_bf16: too many rows");
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
-                       scale_dev, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t, ld_t,
-                       perm16);
+                       scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
+                       ld_t, perm16, ones_row);
     GD_LAUNCH_CHECK();
     return 0;
 }

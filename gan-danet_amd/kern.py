@@ -497,8 +497,11 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta
 
 
 # ---- PAM helpers ------------------------------------------------------------------------------------
-def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, plain_shape=None, t_shape=None,
-              perm16: bool = False):
+LOG2E = 1.4426950408889634    # gd_pam_flash_* take q pre-scaled by log2(e) (include/gandanet.h)
+
+
+def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, scale_imm: float = 1.0, plain_shape=None,
+              t_shape=None, perm16: bool = False, ones_row: int = -1):
     """s: (B, R, Cc)-like fp32 block (per-image dense).  Returns (plain, transposed) bf16 tensors (or None)."""
     sbs = _bview(s, "pack input")
     B = s.shape[0]
@@ -510,8 +513,8 @@ def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, pla
     if t_shape is not None:
         ccp, ldt = t_shape
         tr = torch.empty(B, ccp, ldt, device=s.device, dtype=torch.bfloat16)
-    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), _ptr(plain), rp, ldp, _ptr(tr), ccp, ldt,
-                               int(perm16), _stream()), "gd_pack_bf16")
+    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), float(scale_imm), _ptr(plain), rp, ldp, _ptr(tr),
+                               ccp, ldt, int(perm16), int(ones_row), _stream()), "gd_pack_bf16")
     return plain, tr
 
 
@@ -526,18 +529,16 @@ def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
     return d_raw, delta
 
 
-def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32):
+def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32, v_ones: bool = False):
     # algorithmic (unpadded) work: 2 N^2 (r + C) per image
     with _Bracket("pam_flash_fwd", 2.0 * N * N * (r_alg + Cn) * B):
-        L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, _ptr(gamma), _ptr(x),
-                                       _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()),
+        L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, int(v_ones), _ptr(gamma),
+                                       _ptr(x), _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()),
                 "gd_pam_flash_fwd")
 
 
-def pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32,
-                  c_alg: int = 0):
+def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0):
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
-        L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(qn), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(don),
-                                       _ptr(lse), _ptr(delta), B, N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv),
-                                       _stream()), "gd_pam_flash_bwd")
+        L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(lse), _ptr(delta), B,
+                                       N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv), _stream()), "gd_pam_flash_bwd")

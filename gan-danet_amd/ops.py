@@ -202,9 +202,6 @@ class DenseBlockFn(Function):
 # dual attention: PAM || CAM into one 2C slab      generator.py:104-157
 # =====================================================================================================
 # the pre-v3 dK/dV kernels (GD_PAM_DKV_V3=0, kept for A/B runs) also need q and gamma*dOut channel-major
-_LEGACY_DKV = os.environ.get("GD_PAM_DKV_V3", "1") == "0"
-
-
 def _npad(n: int) -> int:
     return (n + 255) // 256 * 256
 
@@ -219,20 +216,22 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
     N = H * W
     r = wq.shape[0]
     x3 = x.view(B, Cn, N)
-    fused = prec == L.PREC_BF16 and Cn <= 192 and r <= 32
+    fused = prec == L.PREC_BF16 and Cn <= 192 and r <= 31
     q = K.conv2d_fwd(x, wq, bq, 1, 0, prec).view(B, r, N)
     k = K.conv2d_fwd(x, wk, bk, 1, 0, prec).view(B, r, N)
     v = K.conv2d_fwd(x, wv, bv, 1, 0, prec).view(B, Cn, N)
     if fused:
         Np, Cp = _npad(N), _cp(Cn)
-        qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np) if _LEGACY_DKV else None, t_shape=(Np, 32))
-        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True)
-        vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True)
+        # q goes in pre-scaled by log2 e; a spare padded channel of V carries ones (softmax denominator by MFMA)
+        ones = Cp - 1 if Cn < Cp else -1
+        _, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32))
+        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31)
+        vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones)
         del q, k, v
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
-        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r)
-        return True, (qt, kt, qn, kn, vt, o_attn, lse)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0)
+        return True, (qt, kt, kn, vt, o_attn, lse)
     qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)
     s = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
     K.gemm_nt(B=B, M=N, N=N, kseg=1, klen=r, a=qt_, a_bs=N * r, a_ss=0, lda=r, bm=kt_, b_bs=N * r, b_ss=0,
@@ -253,16 +252,15 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
     N = H * W
     r = wq.shape[0]
     if fused:
-        qt, kt, qn, kn, vt, o_attn, lse = pam_saved
+        qt, kt, kn, vt, o_attn, lse = pam_saved
         Np, Cp = _npad(N), _cp(Cn)
         d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
         dgamma_p = K.dot(d_raw, None)
-        don, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, plain_shape=(Cp, Np) if _LEGACY_DKV else None,
-                                t_shape=(Np, Cp))
+        _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, t_shape=(Np, Cp))
         dqn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
-        K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn)
+        K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn)
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
         qt_, kt_, v, p, o_attn = pam_saved

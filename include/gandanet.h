@@ -211,33 +211,41 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
 
 /* ------------------------------------------------------------------------------------------
  * PAM, fused (flash) form in bf16 with fp32 softmax statistics (generator.py:115-122).
- *   qt, kt : (B, Npad, 32) bf16, d zero-padded to 32      (pixel-major)
+ *   qt     : (B, Npad, 32) bf16, d zero-padded to 32, values PRE-SCALED by log2(e)  (gd_pack_bf16 scale_imm):
+ *            the kernels work in the log2 domain and feed the softmax shift in as the MFMA accumulator input
+ *   kt     : (B, Npad, 32) bf16, unscaled, d zero-padded to 31 and d = 31 set to 1.0 (gd_pack_bf16 ones_row = 31):
+ *            the forward feeds its running row maximum through that k-slot (so r <= 31)
  *   v      : (B, Cp, Npad) bf16, Cp = C rounded up to 32   (channel-major, keys perm16-ordered: gd_pack_bf16)
+ *   v_ones : != 0 when channel Cp-1 of v is a row of ones (gd_pack_bf16 ones_row; needs C < Cp): the softmax
+ *            denominator then comes out of the O MFMAs instead of one VALU add per score
  *   x, out : (B, C, N) fp32 with batch strides; out = gamma * attn + x
- *   o_attn : (B, C, N) fp32 un-scaled attention output (kept for backward), lse : (B, N) fp32
+ *   o_attn : (B, C, N) fp32 un-scaled attention output (kept for backward)
+ *   lse    : (B, N) fp32 natural-log log-sum-exp of the unscaled energies.   Npad % 256 == 0.
  * ---------------------------------------------------------------------------------------- */
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
-                     const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn,
-                     float* lse, void* stream);
-/* backward: inputs in both layouts (bf16): qt,kt (B,Npad,32); qn,kn (B,32,Npad) (kn perm16-ordered); vt (B,Npad,Cp);
- * dot (B,Npad,Cp) and don (B,Cp,Npad) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
- * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad).  Two launches: a key-parallel
- * kernel for dK/dV and a query-parallel kernel for dQ (no atomics: bitwise reproducible).  Npad % 256 == 0.
- * qn and don may be NULL: the default dK/dV kernel reads the transposed operands out of qt / dot with LDS
- * transpose reads (they are only needed by the variants selected with GD_PAM_DKV_V3=0). */
-int gd_pam_flash_bwd(const void* qt, const void* kt, const void* qn, const void* kn, const void* vt,
-                     const void* dot_, const void* don, const float* lse, const float* delta, int B, int N,
-                     int Npad, int Cp, float* dqn, float* dkn, float* dv, void* stream);
+                     int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
+                     float* o_attn, float* lse, void* stream);
+/* backward: bf16 inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care); vt (B,Npad,Cp);
+ * dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
+ * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad) -- gradients w.r.t. the
+ * UNSCALED q, k, v.  Two launches: a key-parallel kernel for dK/dV (transposed operands are taken from qt / dot
+ * with LDS transpose reads) and a query-parallel kernel for dQ (no atomics: bitwise reproducible).
+ * Npad % 256 == 0. */
+int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
+                     const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn, float* dkn,
+                     float* dv, void* stream);
 /* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
 int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
                 float* d_raw, float* delta, void* stream);
-/* fp32 (B, R, Cc) planes (batch stride s_bs), optionally times a device scalar -> bf16:
+/* fp32 (B, R, Cc) planes (batch stride s_bs), times scale_imm and optionally times a device scalar -> bf16:
  *   plain      (B, Rp_plain, ld_plain)  zero padded copy          (NULL to skip)
  *   transposed (B, Ccp_t, ld_t)         zero padded transpose     (NULL to skip)
  * perm16 != 0: inside every 16 columns of `plain` the order is [0-3, 8-11, 4-7, 12-15] (the order an MFMA lane
- * half consumes an accumulator-row-ordered k-step: gd_pam_flash_fwd expects its V operand packed this way). */
-int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, void* plain, int Rp_plain,
-                 int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, void* stream);
+ * half consumes an accumulator-row-ordered k-step: gd_pam_flash_fwd expects its V operand packed this way).
+ * ones_row >= 0: that (padding) row of the source is taken as all ones in both outputs (-1: none). */
+int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm, void* plain,
+                 int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, int ones_row,
+                 void* stream);
 
 #ifdef __cplusplus
 }

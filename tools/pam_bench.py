@@ -28,12 +28,13 @@ v = torch.randn(B, C, N, device=dev, generator=g)
 x = torch.randn(B, C, N, device=dev, generator=g)
 do = torch.randn(B, C, N, device=dev, generator=g)
 gamma = torch.full((1,), 0.1, device=dev)
-qn, qt = K.pack_bf16(q, r, N, plain_shape=(32, Np), t_shape=(Np, 32))
-kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True)
-vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True)
+ones = Cp - 1 if C < Cp else -1
+_, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32))
+kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31)
+vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones)
 out, o = torch.empty_like(x), torch.empty_like(x)
 lse = torch.empty(B, N, device=dev)
-don, dot_ = K.pack_bf16(do, C, N, scale=gamma, plain_shape=(Cp, Np), t_shape=(Np, Cp))
+_, dot_ = K.pack_bf16(do, C, N, scale=gamma, t_shape=(Np, Cp))
 dqn = torch.empty(B, 32, Np, device=dev)
 dkn = torch.empty(B, 32, Np, device=dev)
 dv = torch.empty(B, Cp, Np, device=dev)
@@ -53,7 +54,7 @@ def timeit(fn, name, flops):
 
 
 fl = 2.0 * N * N * (r + C) * B
-timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r), "fwd", fl)
+timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0), "fwd", fl)
 d_raw, delta = K.chan_dot(do, o, gamma)
-timeit(lambda: K.pam_flash_bwd(qt, kt, qn, kn, vt, dot_, don, lse, delta, B, N, Np, Cp, dqn, dkn, dv, r_alg=r, c_alg=C),
+timeit(lambda: K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dv, r_alg=r, c_alg=C),
        "bwd", 2 * fl)
