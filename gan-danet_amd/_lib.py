@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgandanet_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LEAKY02 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 
 c_fp = C.c_void_p  # device pointers travel as integers
 
@@ -94,6 +94,11 @@ SIGNATURES = {
     "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
     "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_combine_inputs": (_i, [_p, _i, _i, _i, _f, _p, _i, _i, _i, _f, _p, _i, _i, _i, _p]),
+    "gd_bcast_mul": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
+    "gd_row_dot": (_i, [_p, _p, _p, _l, _l, _p]),
+    "gd_chan_maxmean_fwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
+    "gd_chan_maxmean_bwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
 }
 

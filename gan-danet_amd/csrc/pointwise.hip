@@ -21,6 +21,7 @@ static inline int grid_for(long n, int per_block = 256 * 4) {
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == GD_ACT_RELU) return fmaxf(v, 0.f);
     if (act == GD_ACT_LEAKY02) return v >= 0.f ? v : 0.2f * v;
+    if (act == GD_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
     return v;
 }
 
@@ -35,6 +36,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
         float v = g;
         if (act == GD_ACT_RELU) v = o > 0.f ? g : 0.f;
         else if (act == GD_ACT_LEAKY02) v = o >= 0.f ? g : 0.2f * g;  // sign(y) == sign(x) for leaky
+        else if (act == GD_ACT_SIGMOID) v = g * o * (1.f - o);
         dx[i] = v;
     }
 }
@@ -178,6 +180,59 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
             const int c = c0 + i, r = r0 + tx;
             if (c < Ccp && r < ldt) tr[(long)b * Ccp * ldt + (long)c * ldt + r] = gd_f2bf(tile[tx][i]);
         }
+    }
+}
+
+// ---- attention gates of SqueezeExcitation / CBAMBlock (generator.py:70-101) ------------------------------------
+// y[b][c][p] = x[b][c][p] * att ; mode 0: att[b][c] (channel gate), mode 1: att[b][p] (spatial gate)
+__global__ void bcast_mul_kernel(const float* __restrict__ x, const float* __restrict__ att, float* __restrict__ y, int C,
+                                 long HW, int mode, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long bc = i / HW;
+        const float a = mode == 0 ? att[bc] : att[(bc / C) * HW + (i - bc * HW)];
+        y[i] = x[i] * a;
+    }
+}
+// out[row] = sum_j a[row][j] * b[row][j]
+__global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, long rows, long n) {
+    __shared__ float red[4];
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* ap = a + row * n;
+        const float* bp = b + row * n;
+        float s = 0.f;
+        for (long j = threadIdx.x; j < n; j += 256) s = fmaf(ap[j], bp[j], s);
+        s = gd_block_sum(s, red);
+        if (threadIdx.x == 0) out[row] = s;
+    }
+}
+// y[b][0][p] = max_c x[b][c][p] (first maximal channel -> idx), y[b][1][p] = mean_c x[b][c][p]
+__global__ void chan_maxmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx, int C,
+                                        long HW, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i - b * HW;
+        const float* xp = x + b * C * HW + p;
+        float mx = xp[0], sum = xp[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = xp[(long)c * HW];
+            sum += v;
+            if (v > mx) { mx = v; am = c; }
+        }
+        y[b * 2 * HW + p] = mx;
+        y[b * 2 * HW + HW + p] = sum / (float)C;
+        idx[i] = am;
+    }
+}
+__global__ void chan_maxmean_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* __restrict__ dx,
+                                        int C, long HW, long total) {
+    const float inv_c = 1.f / (float)C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long bc = i / HW, p = i - bc * HW;
+        const long b = bc / C;
+        const int c = (int)(bc - b * C);
+        const float gmax = dy[b * 2 * HW + p], gmean = dy[b * 2 * HW + HW + p];
+        dx[i] = gmean * inv_c + (idx[b * HW + p] == c ? gmax : 0.f);
     }
 }
 
@@ -406,6 +461,33 @@ extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, con
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
                        scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
                        ld_t, perm16, ones_row);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_bcast_mul(const float* x, const float* att, float* y, int B, int C, long HW, int mode, void* stream) {
+    GD_CHECK_ARG(x && att && y && B > 0 && C > 0 && HW > 0 && (mode == 0 || mode == 1), "gd_bcast_mul: bad arguments");
+    const long total = (long)B * C * HW;
+    hipLaunchKernelGGL(bcast_mul_kernel, dim3(grid_for(total)), dim3(256), 0, GD_S, x, att, y, C, HW, mode, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_row_dot(const float* a, const float* b, float* out, long rows, long n, void* stream) {
+    GD_CHECK_ARG(a && b && out && rows > 0 && n > 0, "gd_row_dot: bad arguments");
+    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(256), 0, GD_S, a, b, out, rows, n);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_chan_maxmean_fwd(const float* x, float* y, int* idx, int B, int C, long HW, void* stream) {
+    GD_CHECK_ARG(x && y && idx && B > 0 && C > 0 && HW > 0, "gd_chan_maxmean_fwd: bad arguments");
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(chan_maxmean_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, GD_S, x, y, idx, C, HW, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_chan_maxmean_bwd(const float* dy, const int* idx, float* dx, int B, int C, long HW, void* stream) {
+    GD_CHECK_ARG(dy && idx && dx && B > 0 && C > 0 && HW > 0, "gd_chan_maxmean_bwd: bad arguments");
+    const long total = (long)B * C * HW;
+    hipLaunchKernelGGL(chan_maxmean_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, GD_S, dy, idx, dx, C, HW, total);
     GD_LAUNCH_CHECK();
     return 0;
 }

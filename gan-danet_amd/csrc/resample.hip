@@ -63,6 +63,37 @@ __global__ __launch_bounds__(256) void bicubic_fwd_kernel(const float* __restric
     y[bc * (long)Ho * Wo + (long)oy * Wo + ox] = acc;
 }
 
+// Input preamble of the train step (GAN_DANet_train.ipynb:L218-224): out = cat([bicubic(lr, 1/s1), bicubic(aux, 1/s2)], 1)
+// in ONE launch, written straight into the (B, C1+C2, Ho, Wo) generator input (no separate cat pass).
+// rs1 / rs2 = input/output coordinate ratios (2 and 4 for scale_factor 0.5 / 0.25), antialias off like the reference.
+__global__ __launch_bounds__(256) void combine_inputs_kernel(const float* __restrict__ lr, int C1, int H1, int W1, float rs1,
+                                                            const float* __restrict__ aux, int C2, int H2, int W2,
+                                                            float rs2, float* __restrict__ out, int Ho, int Wo) {
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int oy = blockIdx.y;
+    const int z = blockIdx.z, Ct = C1 + C2;
+    const int b = z / Ct, c = z - b * Ct;
+    if (ox >= Wo) return;
+    const bool first = c < C1;
+    const int Hi = first ? H1 : H2, Wi = first ? W1 : W2;
+    const float rs = first ? rs1 : rs2;
+    const float* p = first ? lr + ((long)b * C1 + c) * H1 * W1 : aux + ((long)b * C2 + (c - C1)) * H2 * W2;
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    cubic_taps(oy, rs, Hi, iy, wy);
+    cubic_taps(ox, rs, Wi, ix, wx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float* row = p + (long)iy[a] * Wi;
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r = fmaf(row[ix[k]], wx[k], r);
+        acc = fmaf(r, wy[a], acc);
+    }
+    out[((long)z * Ho + oy) * Wo + ox] = acc;
+}
+
 // conservative window of output coordinates that may read input coordinate i (cubic: |src - i| < 2 + clamp)
 __device__ __forceinline__ void cubic_window(int i, float rs, int n_in, int n_out, int& lo, int& hi) {
     const float inv = 1.f / rs;
@@ -318,6 +349,18 @@ extern "C" int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, 
     GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bicubic_fwd_kernel, dim3(gd_cdiv(Wo, 256), Ho, nz_), dim3(256), 0,
                                             (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
                                             y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_combine_inputs(const float* lr, int C1, int H1, int W1, float rs1, const float* aux, int C2, int H2,
+                                 int W2, float rs2, float* out, int B, int Ho, int Wo, void* stream) {
+    GD_CHECK_ARG(lr && aux && out, "gd_combine_inputs: null pointer");
+    GD_CHECK_ARG(B > 0 && C1 > 0 && C2 > 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && Ho > 0 && Wo > 0 && Ho <= 65535 &&
+                     (long)B * (C1 + C2) <= 65535 && rs1 > 0.f && rs2 > 0.f,
+                 "gd_combine_inputs: bad sizes");
+    hipLaunchKernelGGL(combine_inputs_kernel, dim3(gd_cdiv(Wo, 256), Ho, B * (C1 + C2)), dim3(256), 0, (hipStream_t)stream,
+                       lr, C1, H1, W1, rs1, aux, C2, H2, W2, rs2, out, Ho, Wo);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .layers import ACT_RELU, BatchNorm2d, Conv2d, ReLU, UpsampleBicubic2x
+from .layers import ACT_RELU, BatchNorm2d, Conv2d, ReLU, Sigmoid, UpsampleBicubic2x
 
 
 class _ConvBnRelu(nn.Sequential):
@@ -191,32 +191,39 @@ class OriginalRelationshipLearner(nn.Module):
 
 
 class SqueezeExcitation(nn.Module):
-    """generator.py:70-84 -- API parity only: not on the training path, not implemented on the HIP path yet."""
+    """generator.py:70-84: global average pool -> 1x1 conv -> ReLU -> 1x1 conv -> sigmoid -> channel gate.
+    Exported by the reference, not built by the train loop."""
 
     def __init__(self, channels: int, reduction_ratio: int = 16) -> None:
         super().__init__()
         red = max(1, channels // reduction_ratio)
-        self.avg_pool = nn.Identity()
+        self.avg_pool = nn.Identity()            # parameter-free slots keep the reference's attribute names
         self.fc1 = Conv2d(channels, red, kernel_size=1)
         self.relu = ReLU()
         self.fc2 = Conv2d(red, channels, kernel_size=1)
-        self.sigmoid = nn.Identity()
+        self.sigmoid = Sigmoid()
 
     def forward(self, x):
-        raise NotImplementedError("SqueezeExcitation is exported for API parity; it is outside the G+D hot path "
-                                  "(SURVEY.md section 8 a14) and has no HIP kernels yet")
+        B, Cn = x.shape[0], x.shape[1]
+        a = ops.global_avg_pool(x).view(B, Cn, 1, 1)
+        a = self.sigmoid(self.fc2(self.fc1(a, ACT_RELU)))
+        return ops.gate_channels(x, a.view(B, Cn))
 
 
 class CBAMBlock(nn.Module):
-    """generator.py:87-101 -- API parity only (see SqueezeExcitation)."""
+    """generator.py:87-101: channel gate (SqueezeExcitation), then a spatial gate from a 7x7 conv over
+    [max_c, mean_c]."""
 
     def __init__(self, channels: int, reduction_ratio: int = 16) -> None:
         super().__init__()
         self.channel_attention = SqueezeExcitation(channels, reduction_ratio)
-        self.spatial_attention = nn.Sequential(nn.Conv2d(2, 1, kernel_size=7, padding=3, bias=False), nn.Identity())
+        self.spatial_attention = nn.Sequential(Conv2d(2, 1, kernel_size=7, padding=3, bias=False), Sigmoid())
 
     def forward(self, x):
-        raise NotImplementedError("CBAMBlock is exported for API parity; it is outside the G+D hot path")
+        x = self.channel_attention(x)
+        B, _, H, W = x.shape
+        a = self.spatial_attention(ops.chan_maxmean(x))
+        return ops.gate_pixels(x, a.view(B, H * W))
 
 
 __all__ = ["OriginalRelationshipLearner", "FlexibleUpsamplingModule", "SqueezeExcitation", "CBAMBlock"]

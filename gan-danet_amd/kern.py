@@ -8,6 +8,7 @@ CPU tensors are rejected -- there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional, Tuple
 
 import torch
@@ -301,6 +302,21 @@ def bicubic_fwd(x: Tensor, Ho: int, Wo: int, rsh: float, rsw: float) -> Tensor:
     return y
 
 
+def combine_inputs(lr: Tensor, aux: Tensor, s1: float = 0.5, s2: float = 0.25) -> Tensor:
+    """cat([bicubic(lr, scale_factor=s1), bicubic(aux, scale_factor=s2)], 1) in one launch
+    (GAN_DANet_train.ipynb:L218-224; output size floor(in * scale) like F.interpolate)"""
+    _dense(lr, "lr_grace_05"), _dense(aux, "hr_aux")
+    B, C1, H1, W1 = lr.shape
+    B2, C2, H2, W2 = aux.shape
+    Ho, Wo = int(math.floor(H1 * s1)), int(math.floor(W1 * s1))
+    if B2 != B or (int(math.floor(H2 * s2)), int(math.floor(W2 * s2))) != (Ho, Wo):
+        raise L.GandanetError(f"combine_inputs: {tuple(lr.shape)} x{s1} and {tuple(aux.shape)} x{s2} do not meet")
+    out = torch.empty(B, C1 + C2, Ho, Wo, device=lr.device, dtype=torch.float32)
+    L.check(lib().gd_combine_inputs(_ptr(lr), C1, H1, W1, 1.0 / s1, _ptr(aux), C2, H2, W2, 1.0 / s2, _ptr(out), B, Ho,
+                                    Wo, _stream()), "gd_combine_inputs")
+    return out
+
+
 def bicubic_bwd(dy: Tensor, Hi: int, Wi: int, rsh: float, rsw: float) -> Tensor:
     _dense(dy, "bicubic dy")
     B, Cn, Ho, Wo = dy.shape
@@ -516,6 +532,43 @@ def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, sca
     L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), float(scale_imm), _ptr(plain), rp, ldp, _ptr(tr),
                                ccp, ldt, int(perm16), int(ones_row), _stream()), "gd_pack_bf16")
     return plain, tr
+
+
+def bcast_mul(x: Tensor, att: Tensor, mode: int) -> Tensor:
+    """x (B, C, H, W) dense times a channel gate att (B, C) [mode 0] or a spatial gate att (B, H*W) [mode 1]"""
+    _dense(x), _dense(att)
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if att.numel() != (B * Cn if mode == 0 else B * HW):
+        raise L.GandanetError(f"bcast_mul: gate of {att.numel()} elements does not match x {tuple(x.shape)} (mode {mode})")
+    y = torch.empty_like(x)
+    L.check(lib().gd_bcast_mul(_ptr(x), _ptr(att), _ptr(y), B, Cn, HW, mode, _stream()), "gd_bcast_mul")
+    return y
+
+
+def row_dot(a: Tensor, b: Tensor, rows: int) -> Tensor:
+    _dense(a), _dense(b)
+    n = a.numel() // rows
+    out = torch.empty(rows, device=a.device, dtype=torch.float32)
+    L.check(lib().gd_row_dot(_ptr(a), _ptr(b), _ptr(out), rows, n, _stream()), "gd_row_dot")
+    return out
+
+
+def chan_maxmean_fwd(x: Tensor):
+    _dense(x)
+    B, Cn, H, W = x.shape
+    y = torch.empty(B, 2, H, W, device=x.device, dtype=torch.float32)
+    idx = torch.empty(B, H * W, device=x.device, dtype=torch.int32)
+    L.check(lib().gd_chan_maxmean_fwd(_ptr(x), _ptr(y), _ptr(idx), B, Cn, H * W, _stream()), "gd_chan_maxmean_fwd")
+    return y, idx
+
+
+def chan_maxmean_bwd(dy: Tensor, idx: Tensor, Cn: int) -> Tensor:
+    _dense(dy)
+    B, _, H, W = dy.shape
+    dx = torch.empty(B, Cn, H, W, device=dy.device, dtype=torch.float32)
+    L.check(lib().gd_chan_maxmean_bwd(_ptr(dy), _ptr(idx), _ptr(dx), B, Cn, H * W, _stream()), "gd_chan_maxmean_bwd")
+    return dx
 
 
 def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):

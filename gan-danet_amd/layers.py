@@ -70,6 +70,11 @@ class ReLU(nn.Module):
         return ops.activation(x, ACT_RELU)
 
 
+class Sigmoid(nn.Module):
+    def forward(self, x):
+        return ops.activation(x, ops.ACT_SIGMOID)
+
+
 class LeakyReLU(nn.Module):
     def __init__(self, negative_slope: float = 0.2, inplace: bool = False) -> None:
         super().__init__()

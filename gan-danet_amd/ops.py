@@ -19,7 +19,7 @@ from . import _lib as L
 from . import kern as K
 from .config import config
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY02
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY02, L.ACT_SIGMOID
 
 
 def _prec() -> int:
@@ -752,3 +752,60 @@ class GlobalAvgPoolFn(Function):
 
 def global_avg_pool(x):
     return GlobalAvgPoolFn.apply(x)
+
+
+# =====================================================================================================
+# attention gates of SqueezeExcitation / CBAMBlock       generator.py:70-101 (exported, not on the train path)
+# =====================================================================================================
+class BcastMulFn(Function):
+    """x (B, C, H, W) * att: mode 0 att (B, C) channel gate (generator.py:84), mode 1 att (B, H*W) spatial gate
+    (generator.py:101)"""
+
+    @staticmethod
+    def forward(ctx, x, att, mode: int):
+        x, att = _c(x), _c(att)
+        ctx.save_for_backward(x, att)
+        ctx.mode = mode
+        return K.bcast_mul(x, att, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, att = ctx.saved_tensors
+        dy = _c(dy)
+        B, Cn = x.shape[0], x.shape[1]
+        dx = K.bcast_mul(dy, att, ctx.mode)
+        if ctx.mode == 0:
+            datt = K.row_dot(dy, x, B * Cn).view_as(att)
+        else:
+            one = torch.ones(1, device=x.device, dtype=torch.float32)
+            datt = K.chan_dot(dy, x, one)[0].view_as(att)
+        return dx, datt, None
+
+
+def gate_channels(x, att):
+    return BcastMulFn.apply(x, att, 0)
+
+
+def gate_pixels(x, att):
+    return BcastMulFn.apply(x, att, 1)
+
+
+class ChanMaxMeanFn(Function):
+    """cat([max over channels, mean over channels], 1)  (generator.py:98-100)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y, idx = K.chan_maxmean_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.channels = x.shape[1]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return K.chan_maxmean_bwd(_c(dy), idx, ctx.channels)
+
+
+def chan_maxmean(x):
+    return ChanMaxMeanFn.apply(x)

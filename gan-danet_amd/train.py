@@ -37,13 +37,17 @@ class GanTrainer:
     def __init__(self, G: nn.Module, D: nn.Module, perceptual: Optional[nn.Module] = None, lr_g: float = 2e-4,
                  lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
                  compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
-                 batch_real_fake: bool = True) -> None:
+                 batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
+        # optional gate on the combined input (the notebook's attention_module / senet_module, L145-171,
+        # L229-232: SqueezeExcitation or CBAMBlock); its parameters join the generator's optimiser (L165-175)
+        self.input_attention = input_attention
+        g_params = list(G.parameters()) + (list(input_attention.parameters()) if input_attention is not None else [])
         ws = world_size()
         self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
-        self.opt_g = AdamW(G.parameters(), lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
+        self.opt_g = AdamW(g_params, lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
         self.red_d = GradReducer(D.parameters())
-        self.red_g = GradReducer(G.parameters())
+        self.red_g = GradReducer(g_params)
         # TVLoss divides by the batch size twice (losses.py:82-87): per-shard TV averaged over ranks is `world`
         # times the single-device global-batch value.  Default = plain DDP semantics (per-shard loss, as the
         # per-shard oracle computes it); set tv_global_batch_semantics to scale it back by 1/world.
@@ -51,9 +55,16 @@ class GanTrainer:
         self.compute_ssim = compute_ssim
         self.batch_real_fake = batch_real_fake
 
+    def step_from_batch(self, lr_grace_05: torch.Tensor, lr_grace_025: torch.Tensor, hr_aux: torch.Tensor,
+                        loss_weight: float) -> StepOutput:
+        """one iteration of the notebook's loader loop (L217-272): the input preamble -- bicubic x0.5 of
+        ``lr_grace_05``, bicubic x0.25 of ``hr_aux``, channel cat (L218-224) -- as one fused launch, then ``step``
+        with ``lr_grace_025`` as the discriminator's real sample / the pixel target"""
+        return self.step(K.combine_inputs(lr_grace_05, hr_aux, 0.5, 0.25), lr_grace_025, loss_weight)
+
     def step(self, x: torch.Tensor, target: torch.Tensor, loss_weight: float) -> StepOutput:
         G, D = self.G, self.D
-        hr = G(x)
+        hr = G(x if self.input_attention is None else self.input_attention(x))
 
         # ---- discriminator update (L246-256) ----
         self.opt_d.zero_grad(set_to_none=True)

@@ -35,7 +35,7 @@ int gd_sizeof_gemm_nt_desc(void);
 
 enum { GD_PREC_FP32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32) */
        GD_PREC_BF16 = 1  /* bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16) */ };
-enum { GD_ACT_NONE = 0, GD_ACT_RELU = 1, GD_ACT_LEAKY02 = 2 };
+enum { GD_ACT_NONE = 0, GD_ACT_RELU = 1, GD_ACT_LEAKY02 = 2, GD_ACT_SIGMOID = 3 };   /* sigmoid: gd_act_fwd/bwd only */
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, "NN" form:   out[b][m][p] = sum_{tap,c} A[b][m][c][tap] * X~[b][c][p (+) tap]
@@ -157,7 +157,13 @@ int gd_bn_act_bwd(const float* dy, long dy_bs, const float* x, long x_bs, const 
 int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, float rscale_h,
                    float rscale_w, void* stream);
 int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, float rscale_h,
-                   float rscale_w, void* stream); /* dx (BC,Hi,Wi) overwritten */
+                   float rscale_w, void* stream);
+/* input preamble of the train step (GAN_DANet_train.ipynb:L218-224), one launch, no cat pass:
+ *   out (B, C1+C2, Ho, Wo) = cat([F.interpolate(lr (B,C1,H1,W1), scale_factor=1/rs1, mode='bicubic'),
+ *                                 F.interpolate(aux (B,C2,H2,W2), scale_factor=1/rs2, mode='bicubic')], dim=1)
+ * align_corners=False, antialias off; rs = input/output coordinate ratio (2.0 and 4.0 in the notebook). */
+int gd_combine_inputs(const float* lr, int C1, int H1, int W1, float rs1, const float* aux, int C2, int H2, int W2,
+                      float rs2, float* out, int B, int Ho, int Wo, void* stream); /* dx (BC,Hi,Wi) overwritten */
 /* y = bilinear(x) (+ y if accumulate) ; or, when res != NULL, y = res + bilinear(x) in one pass: the skip
  * addition of generator.py:245 without a separate copy */
 int gd_bilinear_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int Wo, int accumulate,
@@ -234,6 +240,17 @@ int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn, float* dkn,
                      float* dv, void* stream);
+/* attention gates of SqueezeExcitation / CBAMBlock (generator.py:70-101; exported by the reference, not on the
+ * train path).  Dense (B, C, HW) fp32.
+ *   gd_bcast_mul       : y = x * att; mode 0: att (B, C) channel gate (generator.py:84), mode 1: att (B, HW)
+ *                        spatial gate (generator.py:101).  The data gradient is the same call on dy.
+ *   gd_row_dot         : out[row] = sum_j a[row][j] * b[row][j]   (gate gradient of mode 0; mode 1 uses gd_chan_dot)
+ *   gd_chan_maxmean_*  : y (B, 2, HW) = [max_c x, mean_c x] (generator.py:98-100), idx (B, HW) = arg max;
+ *                        backward routes dy[:,0] to the arg-max channel and spreads dy[:,1] / C */
+int gd_bcast_mul(const float* x, const float* att, float* y, int B, int C, long HW, int mode, void* stream);
+int gd_row_dot(const float* a, const float* b, float* out, long rows, long n, void* stream);
+int gd_chan_maxmean_fwd(const float* x, float* y, int* idx, int B, int C, long HW, void* stream);
+int gd_chan_maxmean_bwd(const float* dy, const int* idx, float* dx, int B, int C, long HW, void* stream);
 /* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
 int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
                 float* d_raw, float* delta, void* stream);

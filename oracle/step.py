@@ -56,6 +56,16 @@ class StepResult:
     hr: torch.Tensor
 
 
+def combine_inputs(lr_grace_05: torch.Tensor, hr_aux: torch.Tensor) -> torch.Tensor:
+    """the loader-loop preamble, GAN_DANet_train.ipynb:L218 (bicubic x0.5 of lr_grace_05), L223 (bicubic x0.25 of
+    hr_aux), L224 (cat on channels); F.interpolate with a scale_factor uses 1/scale as the coordinate ratio and
+    floor(in * scale) as the output size, no antialiasing."""
+    h, w = lr_grace_05.shape[2] // 2, lr_grace_05.shape[3] // 2
+    lr = OF.bicubic_resize(lr_grace_05, h, w, 2.0, 2.0)
+    down = OF.bicubic_resize(hr_aux, hr_aux.shape[2] // 4, hr_aux.shape[3] // 4, 4.0, 4.0)
+    return torch.cat([lr, down], dim=1)
+
+
 def train_step(G: nn.Module, D: nn.Module, opt_g: AdamWState, opt_d: AdamWState, x: torch.Tensor,
                target: torch.Tensor, loss_weight: float, tv_weight: float = 1e-5,
                perceptual: Optional[nn.Module] = None, compute_ssim: bool = True,
@@ -92,6 +102,6 @@ def train_step(G: nn.Module, D: nn.Module, opt_g: AdamWState, opt_d: AdamWState,
         grad_hook(g_params)
     opt_g.apply(g_params)
 
-    return StepResult(float(loss_d), float(loss_g),
+    return StepResult(float(loss_d.detach()), float(loss_g.detach()),
                       {"adv": float(adv), "pix": float(pix), "ssim": float(ssim_term), "tv": float(tv),
                        "perc": float(perc)}, hr.detach())

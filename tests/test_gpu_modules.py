@@ -330,3 +330,104 @@ def test_conv3x3_full_size_shift_property(gd):
     ref1 = torch.zeros(1024, 1024)
     ref1[:-1, :] = xc[0, 0, 1:, :]
     assert torch.equal(y[0, 0], ref0) and torch.equal(y[0, 1], ref1)
+
+
+# ---- SURVEY section 8 rows a14 (exported modules) and f1 (input preamble) ---------------------------------------
+@pytest.mark.parametrize("name,cls", [("se_c32_8x8", "SqueezeExcitation"), ("cbam_c32_8x8", "CBAMBlock")])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_input_gates_vs_reference_fixture(gd, golden_dir, name, cls, prec):
+    """SqueezeExcitation / CBAMBlock (generator.py:70-101; the notebook's optional attention_module, L229-232)"""
+    fx = load_golden(golden_dir, name)
+    m = getattr(gd, cls)(32, 4)
+    fill_module(m)
+    m.to(DEV)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with gd.precision(prec):
+        y = m(x)
+        y.backward(fx["go"].to(DEV))
+    tol_y, tol_g = (1e-4, 1e-3) if prec == "fp32" else (2e-2, 5e-2)
+    assert_close(y, fx["y"], tol_y, "y")
+    assert_close(x.grad, fx["gx"], tol_g, "dx", rell2)
+    _check_param_grads(m, fx, tol_g, rell2)
+
+
+def test_srgand_and_relationship_learner_vs_reference_fixture(gd, golden_dir):
+    fx = load_golden(golden_dir, "srgand_d8_64x64")
+    m = gd.SRGAND(dim=8)
+    fill_module(m)
+    m.to(DEV).train()
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with gd.precision("fp32"):
+        y = m(x)
+        y.backward(fx["go"].to(DEV))
+    assert_close(y, fx["y"], 1e-3, "y")
+    assert_close(x.grad, fx["gx"], 5e-3, "dx", rell2)
+    assert_close(m.bn1.running_mean, fx["rm1"], 1e-4, "running_mean")
+    assert_close(m.bn1.running_var, fx["rv1"], 1e-4, "running_var")
+    _check_param_grads(m, fx, 5e-3, rell2)
+    fx = load_golden(golden_dir, "orl_8ch_8x8")
+    m = gd.OriginalRelationshipLearner(8)
+    fill_module(m)
+    m.to(DEV)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with gd.precision("fp32"):
+        y = m(x)
+        y.backward(seeded((1, 1024, 8, 8), 107).to(DEV))
+    assert_close(y[:, :64], fx["y_head"], 1e-4, "y head")
+    assert_close(y.sum(dim=1), fx["y_sum"], 1e-4, "y channel sum")
+    assert_close(x.grad, fx["gx"], 2e-3, "dx", rell2)
+    _check_param_grads(m, fx, 2e-3, rell2)
+
+
+def test_input_preamble_vs_reference_fixture(gd, golden_dir):
+    """f1: fused bicubic x0.5 / x0.25 + cat (GAN_DANet_train.ipynb:L218-224) against ATen's output, and at the
+    bench geometry (1 + 7 channels -> 256 x 256) against the size-independent property that a constant image stays
+    constant and the two sources land in their own channels"""
+    from gan_danet_amd import kern as K
+    fx = load_golden(golden_dir, "preamble_16x16")
+    out = K.combine_inputs(fx["lr05"].to(DEV), fx["aux"].to(DEV))
+    assert_close(out, fx["combined"], 1e-5, "combined input")
+    lr = torch.full((2, 1, 512, 512), 0.25, device=DEV)
+    aux = torch.arange(7, device=DEV, dtype=torch.float32).view(1, 7, 1, 1).expand(2, 7, 1024, 1024).contiguous()
+    out = K.combine_inputs(lr, aux)
+    assert tuple(out.shape) == (2, 8, 256, 256)
+    ref = torch.cat([torch.full((2, 1, 256, 256), 0.25), torch.arange(7.0).view(1, 7, 1, 1).expand(2, 7, 256, 256)], 1)
+    assert_close(out, ref, 1e-6, "constant planes")
+
+
+def test_trainer_step_from_batch_with_input_gate(gd):
+    """the loader-loop iteration (preamble -> optional SqueezeExcitation gate -> G -> D/G updates) against the
+    oracle restatement of the same lines, fp32 mode"""
+    from oracle import modules as OM
+    from oracle import step as OS
+    from gan_danet_amd import kern as K
+    lr05, aux, tgt = seeded((2, 1, 32, 32), 121), seeded((2, 7, 64, 64), 122), seeded((2, 1, 64, 64), 123)
+    Go, Do, Ao = OM.FlexibleUpsamplingModule(input_channels=8), OM.Discriminator1(), OM.SqueezeExcitation(8, 2)
+    with torch.no_grad():
+        Do(tgt)
+    for m_ in (Go, Do, Ao):
+        fill_module(m_)
+    G, D, A = gd.FlexibleUpsamplingModule(input_channels=8), gd.Discriminator1(), gd.SqueezeExcitation(8, 2)
+    G.load_state_dict(Go.state_dict()), A.load_state_dict(Ao.state_dict())
+    G.to(DEV).train(), A.to(DEV).train(), D.to(DEV).train()
+    with gd.precision("fp32"):
+        with torch.no_grad():
+            D(tgt.to(DEV))
+        D.load_state_dict(Do.state_dict())
+        tr = gd.GanTrainer(G, D, None, input_attention=A)
+        out = tr.step_from_batch(lr05.to(DEV), tgt.to(DEV), aux.to(DEV), 0.5)
+    # oracle: same lines with the gate folded into the generator call
+    class Gated(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.g = Ao, Go
+        def forward(self, x):
+            return self.g(self.a(x))
+    GA = Gated()
+    GA.train()
+    sg, sd = OS.AdamWState(2e-4), OS.AdamWState(4e-4)
+    ro = OS.train_step(GA, Do, sg, sd, OS.combine_inputs(lr05, aux), tgt, 0.5, compute_ssim=False)
+    assert abs(float(out.loss_d) - ro.loss_d) <= 1e-3 * max(1.0, abs(ro.loss_d))
+    assert abs(float(out.loss_g) - ro.loss_g) <= 1e-3 * max(1.0, abs(ro.loss_g))
+    assert_close(A.fc2.weight, Ao.fc2.weight, 1e-3, "gate weights after the step", rell2)
+    assert_close(G.final.weight, Go.final.weight, 1e-3, "G.final after the step", rell2)

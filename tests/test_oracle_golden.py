@@ -125,6 +125,58 @@ def test_discriminator1(golden_dir):
     close(m.fc1.weight.grad[:8, :64], fx["grad__fc1__weight_head"], 1e-4)
 
 
+@pytest.mark.parametrize("name,ctor", [("se_c32_8x8", lambda: OM.SqueezeExcitation(32, 4)),
+                                       ("cbam_c32_8x8", lambda: OM.CBAMBlock(32, 4))])
+def test_input_gates(golden_dir, name, ctor):
+    """SqueezeExcitation / CBAMBlock (generator.py:70-101) against the reference-generated fixtures"""
+    fx = load(golden_dir, name)
+    m = ctor()
+    fill_module(m)
+    x = fx["x"].clone().requires_grad_(True)
+    y = m(x)
+    y.backward(fx["go"])
+    close(y, fx["y"])
+    close(x.grad, fx["gx"], 1e-4)
+    check_grads(m, fx, 1e-4)
+
+
+def test_srgand_and_relationship_learner(golden_dir):
+    """SRGAND (discriminator.py:8-54, train-mode BN) and OriginalRelationshipLearner (generator.py:11-26)"""
+    fx = load(golden_dir, "srgand_d8_64x64")
+    m = OM.SRGAND(dim=8)
+    fill_module(m)
+    m.train()
+    x = fx["x"].clone().requires_grad_(True)
+    y = m(x)
+    y.backward(fx["go"])
+    close(y, fx["y"], 1e-4)
+    close_l2(x.grad, fx["gx"], 1e-3)
+    close(m.bn1.running_mean, fx["rm1"], 1e-4)
+    close(m.bn1.running_var, fx["rv1"], 1e-4)
+    check_grads(m, fx, 1e-3, close_l2)
+    fx = load(golden_dir, "orl_8ch_8x8")
+    m = OM.OriginalRelationshipLearner(8)
+    fill_module(m)
+    x = fx["x"].clone().requires_grad_(True)
+    y = m(x)
+    y.backward(_orl_go())     # the fixture's output gradient is seeded((1, 1024, 8, 8), 107): regenerated, not stored
+    close(y[:, :64], fx["y_head"], 1e-4)
+    close(y.sum(dim=1), fx["y_sum"], 1e-4)
+    close_l2(x.grad, fx["gx"], 1e-3)
+    check_grads(m, fx, 1e-3, close_l2)
+
+
+def _orl_go():
+    from fill import seeded
+    return seeded((1, 1024, 8, 8), 107)
+
+
+def test_input_preamble(golden_dir):
+    """f1: bicubic x0.5 + bicubic x0.25 + cat (GAN_DANet_train.ipynb:L218-224) vs ATen's F.interpolate output"""
+    fx = load(golden_dir, "preamble_16x16")
+    close(OS.combine_inputs(fx["lr05"], fx["aux"]), fx["combined"], 1e-5)
+
+
 def test_losses(golden_dir):
     fx = load(golden_dir, "losses_32x32")
     a = fx["a"].clone().requires_grad_(True)
