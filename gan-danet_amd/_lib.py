@@ -94,6 +94,14 @@ SIGNATURES = {
     "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
     "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
+    "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gd_nhwc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
+    "gd_nhwc_stem_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "gd_nhwc_maxpool2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "gd_nhwc_maxpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "gd_nhwc_l1": (_i, [_p, _p, _l, _p, _i, _p, _p]),
+    "gd_nhwc_l1_grad": (_i, [_p, _p, _l, _p, _i, _p, _p]),
     "gd_combine_inputs": (_i, [_p, _i, _i, _i, _f, _p, _i, _i, _i, _f, _p, _i, _i, _i, _p]),
     "gd_bcast_mul": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
     "gd_row_dot": (_i, [_p, _p, _p, _l, _l, _p]),

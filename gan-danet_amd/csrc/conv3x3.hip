@@ -244,6 +244,232 @@ extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, voi
 }
 
 // =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolution on NHWC bf16 activations (the frozen VGG19 feature stack of PerceptualLoss,
+// losses.py:13-73: forward AND data gradient, which is the same operator with transposed / flipped weights).
+// With pixel-major bf16 storage a patch pixel's 32-channel chunk is 64 contiguous bytes: staging is four 16-byte
+// copies per pixel (no gather, no convert), prefetched into registers under the previous chunk's MFMAs, and the
+// tensor is read and written at 2 bytes per element.  Same tile / fragment scheme as conv3x3_halo_kernel.
+// Epilogue: (+ bias) (ReLU) (* [mask > 0]: backward of the ReLU that produced `mask`) (+ res) -> bf16 NHWC.
+// =====================================================================================================
+namespace {
+
+struct NhwcConvArgs {
+    const unsigned short* x;      // (B, H, W, K) bf16
+    const unsigned short* wp;     // packed weights [m-tile][chunk][tap][BM][32]
+    const float* bias;            // (M) or null
+    const unsigned short* mask;   // (B, H, W, M) bf16 or null
+    const unsigned short* res;    // (B, H, W, M) bf16 or null
+    unsigned short* y;            // (B, H, W, M) bf16
+    int H, W, K, M, relu, tiles_x, nchunks;
+};
+
+template <int BM>
+__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs a) {
+    constexpr int TH = 8;
+    constexpr int WAVES_M = 2, WAVES_N = 2;
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int TN = TH / WAVES_N;
+    constexpr int PH = TH + 2, NPIX = PH * PW;
+    constexpr int WCHUNKS = 3 * BM * CK / 8;
+    constexpr int WPT = WCHUNKS / 256;
+    constexpr int NIT = (4 * NPIX + 255) / 256;       // 16-byte staging items (pixel, channel octet) per thread
+    static_assert(WCHUNKS % 256 == 0, "weight stage must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) unsigned short patch[NPIX * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short wts[3 * BM * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z, mt = blockIdx.y;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = a.H, W = a.W, K = a.K;
+    const unsigned short* ximg = a.x + (long)b * H * W * K;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const unsigned short* wbase = a.wp + (long)mt * a.nchunks * 9 * BM * CK;
+    u32x4_t wreg[WPT];
+    auto load_w = [&](int chunk, int ky) {
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(wbase + ((long)chunk * 9 + ky * 3) * BM * CK);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[i] = src[tid + i * 256];
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int v = tid + i * 256;
+            const int row = v >> 2, q = v & 3;
+            *reinterpret_cast<u32x4_t*>(wts + row * LD + q * 8) = wreg[i];
+        }
+    };
+
+    // staging plan, fixed per thread: element offset of the item inside the image (channel 0 of the chunk) and its
+    // LDS slot; bit `it` of inmask: the pixel lies inside the image (else zero padding)
+    unsigned int goff[NIT], inmask = 0, slotmask = 0;
+    int loff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int w = tid + it * 256;
+        const int pix = w >> 2, q = w & 3;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool slot = w < 4 * NPIX;
+        const bool inside = slot && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        loff[it] = pix * LD + q * 8;
+        goff[it] = inside ? (unsigned int)(((long)iy * W + ix) * K + q * 8) : 0u;
+        inmask |= inside ? (1u << it) : 0u;
+        slotmask |= slot ? (1u << it) : 0u;
+    }
+    u32x4_t raw[NIT];
+    auto load_patch = [&](int chunk) {
+        const unsigned short* base = ximg + chunk * CK;       // wave-uniform
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = (tid + it * 256) & 3;
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            raw[it] = (((inmask >> it) & 1u) && chunk * CK + q * 8 < K) ? *reinterpret_cast<const u32x4_t*>(base + goff[it]) : z;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if ((slotmask >> it) & 1u) *reinterpret_cast<u32x4_t*>(patch + loff[it]) = raw[it];
+    };
+
+    load_patch(0);
+    store_patch();
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        load_w(chunk, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            store_w();
+            __syncthreads();
+            if (ky == 0 && chunk + 1 < a.nchunks) load_patch(chunk + 1);   // lands under this chunk's MFMAs
+            if (ky < 2) load_w(chunk, ky + 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int ks = 0; ks < CK / 16; ++ks) {
+                    bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = *reinterpret_cast<const bf16x8_t*>(wts + (kx * BM + wm * TM * 32 + i * 32 + r) * LD +
+                                                                  ks * 16 + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + ((wn * TN + j + ky) * PW + r + kx) * LD +
+                                                                  ks * 16 + 8 * h);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8_native_t, fa[i]), __builtin_bit_cast(bf16x8_native_t, fb[j]),
+                                acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        if (chunk + 1 < a.nchunks) store_patch();       // published by the next chunk's first barrier
+    }
+
+    // ---- epilogue: lane = pixel, accumulator registers 4g..4g+3 = four consecutive output channels (8-byte stores) ----
+    const int ox = x0 + r;
+    if (ox < W) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int oy = y0 + wn * TN + j;
+            if (oy >= H) continue;
+            const long pbase = (((long)b * H + oy) * W + ox) * a.M;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = mt * BM + wm * TM * 32 + i * 32 + 8 * g + 4 * h;
+                    if (m >= a.M) continue;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[i][j][4 * g + k];
+                        if (a.bias) v[k] += a.bias[m + k];
+                        if (a.relu) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    if (a.mask) {
+                        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + pbase + m);
+                        // bf16 > 0  <=>  sign clear and magnitude non-zero
+                        if (!((mk.x & 0x7FFFu) && !(mk.x & 0x8000u))) v[0] = 0.f;
+                        if (!((mk.x >> 16) & 0x7FFFu) || (mk.x >> 31)) v[1] = 0.f;
+                        if (!((mk.y & 0x7FFFu) && !(mk.y & 0x8000u))) v[2] = 0.f;
+                        if (!((mk.y >> 16) & 0x7FFFu) || (mk.y >> 31)) v[3] = 0.f;
+                    }
+                    if (a.res) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(a.res + pbase + m);
+                        v[0] += gd_bf2f((unsigned short)(rr.x & 0xFFFFu));
+                        v[1] += gd_bf2f((unsigned short)(rr.x >> 16));
+                        v[2] += gd_bf2f((unsigned short)(rr.y & 0xFFFFu));
+                        v[3] += gd_bf2f((unsigned short)(rr.y >> 16));
+                    }
+                    uint2 o;
+                    o.x = gd_pack_bf2(v[0], v[1]);
+                    o.y = gd_pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a.y + pbase + m) = o;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator image in ws (gd_conv3x3_ws_bytes(M, K) bytes with
+// (M, K) = (Cout, Cin) for the forward operator, (Cin, Cout) for transposed != 0 = the data-gradient operator)
+extern "C" int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int transposed, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    GD_CHECK_ARG(w && ws && Cout > 0 && Cin > 0, "gd_conv3x3_nhwc_pack: bad arguments");
+    const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+    GD_CHECK_ARG(ws_bytes >= gd_conv3x3_ws_bytes(M, K), "gd_conv3x3_nhwc_pack: workspace too small");
+    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const int mtiles = (M + bm - 1) / bm, nchunks = (K + CK - 1) / CK;
+    const long total = (long)mtiles * nchunks * 9 * bm * CK;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    const long sm = transposed ? 9 : (long)Cin * 9, sc = transposed ? (long)Cin * 9 : 9;
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, sm, sc, 1L, M, K,
+                       transposed ? 1 : 0, bm, nchunks, (unsigned short*)ws, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bias, const void* mask, const void* res,
+                               void* y, int B, int H, int W, int K, int M, int relu, void* stream) {
+    GD_CHECK_ARG(x && wpack && y, "gd_conv3x3_nhwc: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0,
+                 "gd_conv3x3_nhwc: channel counts must be multiples of 8");
+    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc: image too large");
+    NhwcConvArgs a;
+    a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
+    a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
+    a.H = H; a.W = W; a.K = K; a.M = M; a.relu = relu;
+    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const int mtiles = (M + bm - 1) / bm;
+    a.nchunks = (K + CK - 1) / CK;
+    a.tiles_x = (W + TW - 1) / TW;
+    const int tiles_y = (H + 7) / 8;
+    dim3 grid(a.tiles_x * tiles_y, mtiles, B);
+    if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================================
 // weight gradient of the 3x3 / stride 1 / pad 1 convolution
 //   dW[co][ci][tap] = sum_{b,y,x} dY[b][co][y][x] * X~[b][ci][y+ky-1][x+kx-1]
 // GEMM view per tap: M = co, N = ci, K = pixels.  A workgroup owns BM = 32*NW output channels x one 32-channel

@@ -1,0 +1,274 @@
+// Pixel-major (NHWC) bf16 activation kernels for the frozen VGG19 feature stack of PerceptualLoss
+// (losses.py:13-73; torchvision vgg19.features[:21]): the 3-channel stem conv and its data gradient, 2x2 max
+// pooling forward / backward, and the L1 feature distance with its (ReLU-masked) gradient.  The 3x3 convs
+// between them are gd_conv3x3_nhwc (conv3x3.hip).  All HBM-bound: 16-byte accesses (8 channels) per lane,
+// lanes = consecutive channel octets of consecutive pixels.
+#include "common.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[2 * k] = gd_bf2f((unsigned short)(v[k] & 0xFFFFu));
+        f[2 * k + 1] = gd_bf2f((unsigned short)(v[k] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    const u32x4_t v = {gd_pack_bf2(f[0], f[1]), gd_pack_bf2(f[2], f[3]), gd_pack_bf2(f[4], f[5]), gd_pack_bf2(f[6], f[7])};
+    return v;
+}
+
+// ---- stem: fp32 NCHW image (B, Ci <= 4, H, W) -> conv3x3 p1 (+bias, ReLU) -> NHWC bf16 (B, H, W, Co) --------------
+// thread = (pixel, output-channel octet); weights in LDS as [ci][tap][co]
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int Ci, int H, int W,
+                                                      const float* __restrict__ w, const float* __restrict__ bias, int Co,
+                                                      int relu, unsigned short* __restrict__ y, long npix_total) {
+    extern __shared__ float wl[];                       // Ci * 9 * Co
+    for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
+        const int co = i % Co, t = (i / Co) % 9, ci = i / (9 * Co);
+        wl[i] = w[((long)co * Ci + ci) * 9 + t];
+    }
+    __syncthreads();
+    const int oct = Co / 8;
+    const long HW = (long)H * W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < npix_total * oct; idx += (long)gridDim.x * 256) {
+        const long p = idx / oct;
+        const int o8 = (int)(idx - p * oct) * 8;
+        const long b = p / HW;
+        const int rem = (int)(p - b * HW);
+        const int py = rem / W, px = rem - py * W;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = bias ? bias[o8 + k] : 0.f;
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float* plane = img + (b * Ci + ci) * HW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float v = plane[(long)iy * W + ix];
+                const float* wp = wl + (ci * 9 + t) * Co + o8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wp[k], acc[k]);
+            }
+        }
+        if (relu)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
+        *reinterpret_cast<u32x4_t*>(y + p * Co + o8) = pack8(acc);
+    }
+}
+
+// data gradient of the stem: g (B, H, W, Co) bf16 -> dimg (B, Ci, H, W) fp32;  thread = pixel
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const unsigned short* __restrict__ g, int Ci, int H, int W,
+                                                      const float* __restrict__ w, int Co, float* __restrict__ dimg,
+                                                      long npix_total) {
+    extern __shared__ float wl[];                       // [ci][tap][co]
+    for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
+        const int co = i % Co, t = (i / Co) % 9, ci = i / (9 * Co);
+        wl[i] = w[((long)co * Ci + ci) * 9 + t];
+    }
+    __syncthreads();
+    const long HW = (long)H * W;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix_total; p += (long)gridDim.x * 256) {
+        const long b = p / HW;
+        const int rem = (int)(p - b * HW);
+        const int py = rem / W, px = rem - py * W;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // output pixel q = p - (tap offset) read input pixel p through tap t
+            const int qy = py - (t / 3 - 1), qx = px - (t % 3 - 1);
+            if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+            const unsigned short* gp = g + ((b * H + qy) * (long)W + qx) * Co;
+            for (int o8 = 0; o8 < Co; o8 += 8) {
+                float f[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(gp + o8), f);
+                for (int ci = 0; ci < Ci; ++ci) {
+                    const float* wp = wl + (ci * 9 + t) * Co + o8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[ci] = fmaf(f[k], wp[k], acc[ci]);
+                }
+            }
+        }
+        for (int ci = 0; ci < Ci; ++ci) dimg[(b * Ci + ci) * HW + rem] = acc[ci];
+    }
+}
+
+// ---- 2x2 max pooling, NHWC bf16; thread = (output pixel, channel octet) --------------------------------------------
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const unsigned short* __restrict__ x, int H, int W, int C,
+                                                      unsigned short* __restrict__ y, long total) {
+    const int oct = C / 8, Ho = H / 2, Wo = W / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx / oct;
+        const int o8 = (int)(idx - p * oct) * 8;
+        const long b = p / ((long)Ho * Wo);
+        const int rem = (int)(p - b * (long)Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const unsigned short* xp = x + ((b * H + 2 * oy) * (long)W + 2 * ox) * C + o8;
+        float m[8], f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(xp), m);
+        const long offs[3] = {(long)C, (long)W * C, (long)W * C + C};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(xp + offs[q]), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], f[k]);
+        }
+        *reinterpret_cast<u32x4_t*>(y + p * C + o8) = pack8(m);
+    }
+}
+// dx = dy at the FIRST maximum of each window in row-major order (ATen's tie rule), else 0; with relu_mask the
+// result is also gated by x > 0 (backward of the ReLU that produced x)
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                      int H, int W, int C, int relu_mask, unsigned short* __restrict__ dx,
+                                                      long total) {
+    const int oct = C / 8, Ho = H / 2, Wo = W / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx / oct;
+        const int o8 = (int)(idx - p * oct) * 8;
+        const long b = p / ((long)Ho * Wo);
+        const int rem = (int)(p - b * (long)Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const long base = ((b * H + 2 * oy) * (long)W + 2 * ox) * C + o8;
+        const long offs[4] = {0L, (long)C, (long)W * C, (long)W * C + C};
+        float v[4][8], g[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unpack8(*reinterpret_cast<const u32x4_t*>(x + base + offs[q]), v[q]);
+        unpack8(*reinterpret_cast<const u32x4_t*>(dy + p * C + o8), g);
+        float out[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int arg = 0;
+            float m = v[0][k];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (v[q][k] > m) { m = v[q][k]; arg = q; }
+            const float gk = (relu_mask && !(m > 0.f)) ? 0.f : g[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q][k] = q == arg ? gk : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(dx + base + offs[q]) = pack8(out[q]);
+    }
+}
+
+// ---- L1 feature distance: partial sums of |a - b| (two-stage, deterministic) and its gradient ----------------------
+__global__ __launch_bounds__(256) void l1_sum_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                    long n8, float* __restrict__ ws) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float fa[8], fb[8];
+        unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
+        unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += fabsf(fa[k] - fb[k]);
+    }
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ ws, int nparts, float scale,
+                                                      float* __restrict__ out, int accumulate) {
+    __shared__ double redd[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += ws[i];
+    acc = gd_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)((redd[0] + redd[1] + redd[2] + redd[3]) * (double)scale);
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+// g = (*upstream) * inv_n * sign(a - b), gated by a > 0 when relu_mask (a is a ReLU output)
+__global__ __launch_bounds__(256) void l1_grad_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                     long n8, const float* __restrict__ upstream, float inv_n, int relu_mask,
+                                                     unsigned short* __restrict__ g) {
+    const float k = (*upstream) * inv_n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float fa[8], fb[8], o[8];
+        unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
+        unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dv = fa[j] - fb[j];
+            float v = dv > 0.f ? k : (dv < 0.f ? -k : 0.f);
+            if (relu_mask && !(fa[j] > 0.f)) v = 0.f;
+            o[j] = v;
+        }
+        reinterpret_cast<u32x4_t*>(g)[i] = pack8(o);
+    }
+}
+
+static inline int grid_n(long n, int cap = 16384) {
+    long g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+#define NS(s) ((hipStream_t)(s))
+
+extern "C" int gd_nhwc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co,
+                                int relu, void* y, void* stream) {
+    GD_CHECK_ARG(img && w && y && B > 0 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Ci * 9 * Co * 4 <= 65536,
+                 "gd_nhwc_stem_fwd: needs Ci <= 4, Co % 8 == 0");
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid_n(npix * (Co / 8))), dim3(256), (size_t)Ci * 9 * Co * 4, NS(stream), img, Ci,
+                       H, W, w, bias, Co, relu, (unsigned short*)y, npix);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg,
+                                void* stream) {
+    GD_CHECK_ARG(g && w && dimg && B > 0 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Ci * 9 * Co * 4 <= 65536,
+                 "gd_nhwc_stem_bwd: needs Ci <= 4, Co % 8 == 0");
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid_n(npix)), dim3(256), (size_t)Ci * 9 * Co * 4, NS(stream),
+                       (const unsigned short*)g, Ci, H, W, w, Co, dimg, npix);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, void* stream) {
+    GD_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
+                 "gd_nhwc_maxpool2_fwd: needs even H, W and C % 8 == 0");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)x, H, W, C,
+                       (unsigned short*)y, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx,
+                                    void* stream) {
+    GD_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
+                 "gd_nhwc_maxpool2_bwd: needs even H, W and C % 8 == 0");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)x,
+                       (const unsigned short*)dy, H, W, C, relu_mask, (unsigned short*)dx, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && n > 0 && n % 8 == 0, "gd_nhwc_l1: n must be a positive multiple of 8");
+    const int g = grid_n(n / 8, 1024);
+    hipLaunchKernelGGL(l1_sum_kernel, dim3(g), dim3(256), 0, NS(stream), (const unsigned short*)a, (const unsigned short*)b,
+                       n / 8, ws);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, NS(stream), ws, g, (float)(1.0 / (double)n), out, accumulate);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g,
+                               void* stream) {
+    GD_CHECK_ARG(a && b && upstream && g && n > 0 && n % 8 == 0, "gd_nhwc_l1_grad: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_n(n / 8)), dim3(256), 0, NS(stream), (const unsigned short*)a,
+                       (const unsigned short*)b, n / 8, upstream, (float)(1.0 / (double)n), relu_mask, (unsigned short*)g);
+    GD_LAUNCH_CHECK();
+    return 0;
+}

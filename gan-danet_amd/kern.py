@@ -595,3 +595,93 @@ def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
         L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(lse), _ptr(delta), B,
                                        N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv), _stream()), "gd_pam_flash_bwd")
+
+
+# =====================================================================================================
+# NHWC bf16 kernels (frozen VGG19 feature stack of PerceptualLoss)
+# =====================================================================================================
+def _bf(t: Tensor, name: str = "tensor") -> Tensor:
+    _chk(t, name, torch.bfloat16)
+    if not t.is_contiguous():
+        raise L.GandanetError(f"{name}: expected a contiguous tensor, got strides {t.stride()}")
+    return t
+
+
+def conv3x3_nhwc_pack(w: Tensor, transposed: bool) -> Tensor:
+    """w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator (forward, or the data-gradient operator when transposed)"""
+    _dense(w, "conv weight")
+    Cout, Cin = w.shape[0], w.shape[1]
+    M, Kc = (Cin, Cout) if transposed else (Cout, Cin)
+    nbytes = int(lib().gd_conv3x3_ws_bytes(M, Kc))
+    ws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    L.check(lib().gd_conv3x3_nhwc_pack(_ptr(w), Cout, Cin, int(transposed), _ptr(ws), nbytes, _stream()),
+            "gd_conv3x3_nhwc_pack")
+    return ws
+
+
+def conv3x3_nhwc(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, relu: bool = False,
+                 mask: Optional[Tensor] = None, res: Optional[Tensor] = None) -> Tensor:
+    """x (B, H, W, K) bf16 -> (B, H, W, M) bf16: [mask > 0] * act(conv3x3(x) + bias) + res"""
+    _bf(x, "nhwc conv input")
+    B, H, W, Kc = x.shape
+    y = torch.empty(B, H, W, M, device=x.device, dtype=torch.bfloat16)
+    for t, nm in ((mask, "mask"), (res, "res")):
+        if t is not None and (_bf(t, nm).shape != y.shape):
+            raise L.GandanetError(f"conv3x3_nhwc: {nm} {tuple(t.shape)} does not match the output {tuple(y.shape)}")
+    with _Bracket("conv3x3_nhwc", 2.0 * 9 * Kc * M * H * W * B):
+        L.check(lib().gd_conv3x3_nhwc(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(mask), _ptr(res), _ptr(y), B, H, W, Kc, M,
+                                      int(relu), _stream()), "gd_conv3x3_nhwc")
+    return y
+
+
+def nhwc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+    _dense(img, "stem image"), _dense(w, "stem weight")
+    B, Ci, H, W = img.shape
+    Co = w.shape[0]
+    if w.shape[1] != Ci:
+        raise L.GandanetError(f"nhwc_stem_fwd: weight {tuple(w.shape)} does not match image {tuple(img.shape)}")
+    y = torch.empty(B, H, W, Co, device=img.device, dtype=torch.bfloat16)
+    L.check(lib().gd_nhwc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, int(relu), _ptr(y), _stream()),
+            "gd_nhwc_stem_fwd")
+    return y
+
+
+def nhwc_stem_bwd(g: Tensor, w: Tensor) -> Tensor:
+    _bf(g, "stem gradient"), _dense(w, "stem weight")
+    B, H, W, Co = g.shape
+    Ci = w.shape[1]
+    dimg = torch.empty(B, Ci, H, W, device=g.device, dtype=torch.float32)
+    L.check(lib().gd_nhwc_stem_bwd(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), _stream()), "gd_nhwc_stem_bwd")
+    return dimg
+
+
+def nhwc_maxpool2_fwd(x: Tensor) -> Tensor:
+    _bf(x, "pool input")
+    B, H, W, Cn = x.shape
+    y = torch.empty(B, H // 2, W // 2, Cn, device=x.device, dtype=torch.bfloat16)
+    L.check(lib().gd_nhwc_maxpool2_fwd(_ptr(x), B, H, W, Cn, _ptr(y), _stream()), "gd_nhwc_maxpool2_fwd")
+    return y
+
+
+def nhwc_maxpool2_bwd(x: Tensor, dy: Tensor, relu_mask: bool) -> Tensor:
+    _bf(x, "pool input"), _bf(dy, "pool dy")
+    B, H, W, Cn = x.shape
+    dx = torch.empty_like(x)
+    L.check(lib().gd_nhwc_maxpool2_bwd(_ptr(x), _ptr(dy), B, H, W, Cn, int(relu_mask), _ptr(dx), _stream()),
+            "gd_nhwc_maxpool2_bwd")
+    return dx
+
+
+def nhwc_l1(a: Tensor, b: Tensor, out: Tensor, accumulate: bool) -> None:
+    """out[0] (+)= mean |a - b| over bf16 tensors of equal shape"""
+    _bf(a, "l1 a"), _bf(b, "l1 b")
+    ws = torch.empty(1024, device=a.device, dtype=torch.float32)
+    L.check(lib().gd_nhwc_l1(_ptr(a), _ptr(b), a.numel(), _ptr(out), int(accumulate), _ptr(ws), _stream()), "gd_nhwc_l1")
+
+
+def nhwc_l1_grad(a: Tensor, b: Tensor, upstream: Tensor, relu_mask: bool) -> Tensor:
+    _bf(a, "l1 a"), _bf(b, "l1 b"), _dense(upstream, "upstream gradient")
+    g = torch.empty_like(a)
+    L.check(lib().gd_nhwc_l1_grad(_ptr(a), _ptr(b), a.numel(), _ptr(upstream), int(relu_mask), _ptr(g), _stream()),
+            "gd_nhwc_l1_grad")
+    return g

@@ -90,7 +90,60 @@ class PerceptualLoss(nn.Module):
             i += 1
         return feats
 
+    def _nhwc_plan(self):
+        """layer plan + packed operators of the pixel-major bf16 path, or None when the configuration is not
+        served by it (taps off ReLU indices or directly before a pool, non-VGG stacks).  Cached; rebuilt when a
+        weight tensor changes (load_state_dict)."""
+        from . import kern as K
+        convs = [m for m in self.vgg if isinstance(m, Conv2d)]
+        version = tuple((id(c.weight), c.weight._version, c.weight.device) for c in convs)
+        cached = getattr(self, "_nhwc_cache", None)
+        if cached is not None and cached[0] == version:
+            return cached[1]
+        plan = None
+        n = len(self.vgg)
+        ok = n >= 2 and isinstance(self.vgg[0], Conv2d) and self.vgg[0].weight.shape[1] == 3 and n - 1 in self.feature_layers
+        pairs, ops_, taps = [], [], set()
+        i = 0
+        while ok and i < n:
+            m = self.vgg[i]
+            if isinstance(m, Conv2d):
+                if not (i + 1 < n and isinstance(self.vgg[i + 1], ReLU)) or i in self.feature_layers:
+                    ok = False
+                    break
+                k = len(pairs)
+                w = m.weight.detach()
+                if k == 0:
+                    ops_.append(("stem", k, m.bias.detach()))
+                    pairs.append([k, False, None, 3])
+                else:
+                    ops_.append(("conv", k, m.bias.detach(), K.conv3x3_nhwc_pack(w, False), w.shape[0]))
+                    pairs.append([k, False, K.conv3x3_nhwc_pack(w, True), w.shape[1]])
+                if i + 1 in self.feature_layers:
+                    taps.add(k)
+                i += 2
+            elif isinstance(m, _MaxPool2):
+                if not pairs or pairs[-1][1] or (len(pairs) - 1) in taps or i in self.feature_layers:
+                    ok = False
+                    break
+                pairs[-1][1] = True
+                ops_.append(("pool", -1))
+                i += 1
+            else:
+                ok = False
+        if ok and pairs and not pairs[-1][1] and (len(pairs) - 1) in taps:
+            w0 = self.vgg[0].weight.detach()
+            plan = {"ops": ops_, "pairs": [tuple(p) for p in pairs], "taps": taps,
+                    # 1-channel inputs are repeated to 3 channels (losses.py:65-68): conv(repeat(x)) = conv_{sum_c w}(x)
+                    "w0": {3: w0.contiguous(), 1: w0.sum(dim=1, keepdim=True).contiguous()}}
+        self._nhwc_cache = (version, plan)
+        return plan
+
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        from .config import config
+        if (config.precision == "bf16" and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
+                and x.shape[3] % 8 == 0 and self._nhwc_plan() is not None):
+            return _PerceptualNhwcFn.apply(x, y, self)
         x3 = x if x.shape[1] == 3 else ops.repeat_channels(x, 3)
         y3 = y if y.shape[1] == 3 else ops.repeat_channels(y, 3)
         with torch.no_grad():
@@ -98,6 +151,66 @@ class PerceptualLoss(nn.Module):
         fx = self._features(x3)
         terms = [ops.l1_loss(fx[i], fy[i]) for i in sorted(self.feature_layers)]
         return ops.weighted_sum([1.0] * len(terms), terms)
+
+
+class _PerceptualNhwcFn(torch.autograd.Function):
+    """The whole perceptual term as ONE autograd node on pixel-major bf16 activations (bf16 mode): stem conv
+    from the fp32 image, gd_conv3x3_nhwc for every other conv (+bias+ReLU fused), NHWC max-pool, L1 feature
+    distances; the backward walks the frozen stack with the data-gradient operators, the ReLU backward fused into
+    each producer (mask = the saved ReLU output) and the tap gradients added through the epilogue's ``res``."""
+
+    @staticmethod
+    def forward(ctx, x, y, mod):
+        from . import kern as K
+        plan = mod._nhwc_plan()
+        x, y = x.contiguous(), y.contiguous()
+        dev = x.device
+
+        def run(img, keep_all):
+            """returns {pair index: ReLU output} (all pairs when keep_all, else only the tapped ones)"""
+            kept = {}
+            a = None
+            for op in plan["ops"]:
+                if op[0] == "stem":
+                    a = K.nhwc_stem_fwd(img, plan["w0"][img.shape[1]], op[2], True)
+                elif op[0] == "conv":
+                    a = K.conv3x3_nhwc(a, op[3], op[2], op[4], relu=True)
+                else:
+                    a = K.nhwc_maxpool2_fwd(a)
+                    continue
+                if keep_all or op[1] in plan["taps"]:
+                    kept[op[1]] = a
+            return kept
+
+        with torch.no_grad():
+            fy = run(y, False)
+            fx = run(x, True)
+            loss = torch.zeros(1, device=dev, dtype=torch.float32)
+            for n, k in enumerate(sorted(plan["taps"])):
+                K.nhwc_l1(fx[k], fy[k], loss, accumulate=n > 0)
+        ctx.plan, ctx.fx, ctx.fy, ctx.ci = plan, fx, fy, x.shape[1]
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import kern as K
+        plan, fx, fy = ctx.plan, ctx.fx, ctx.fy
+        up = dloss.reshape(1).to(torch.float32).contiguous()
+        pairs = plan["pairs"]                 # forward order: (pair index, followed_by_pool, dgrad pack, Cin)
+        top = len(pairs) - 1
+        g = K.nhwc_l1_grad(fx[top], fy[top], up, True)          # w.r.t. the top conv's pre-activation
+        for k in range(top - 1, -1, -1):
+            _, pooled, _, _ = pairs[k]
+            _, _, pack_t, cin_next = pairs[k + 1]
+            if pooled:
+                dpool = K.conv3x3_nhwc(g, pack_t, None, cin_next)
+                g = K.nhwc_maxpool2_bwd(fx[k], dpool, True)
+            else:
+                res = K.nhwc_l1_grad(fx[k], fy[k], up, True) if k in plan["taps"] else None
+                g = K.conv3x3_nhwc(g, pack_t, None, cin_next, mask=fx[k], res=res)
+        dx = K.nhwc_stem_bwd(g, plan["w0"][ctx.ci])
+        ctx.fx = ctx.fy = None
+        return dx, None, None
 
 
 class TVLoss(nn.Module):

@@ -216,6 +216,31 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
              float eps, float weight_decay, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Pixel-major (NHWC) bf16 kernels for the frozen VGG19 feature stack of PerceptualLoss (losses.py:13-73;
+ * torchvision vgg19.features[:21]).  Activations (B, H, W, C) bf16, C % 8 == 0.
+ *   gd_conv3x3_nhwc_pack : w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator in ws; transposed != 0 packs the
+ *                          data-gradient operator (channels swapped, taps flipped).  ws needs
+ *                          gd_conv3x3_ws_bytes(M, K) bytes, (M, K) = (Cout, Cin) or (Cin, Cout).
+ *   gd_conv3x3_nhwc      : y = [mask > 0] * act(conv3x3_p1(x) + bias) + res   (x: K channels, y/mask/res: M channels;
+ *                          bias, mask, res may be NULL; mask = the ReLU output whose backward is being applied)
+ *   gd_nhwc_stem_fwd/bwd : first conv (features[0], Ci <= 4 input channels) from / to the fp32 NCHW image
+ *   gd_nhwc_maxpool2_*   : nn.MaxPool2d(2); backward takes the pooled layer's input x (first maximum wins, ATen's
+ *                          tie rule) and optionally gates by x > 0
+ *   gd_nhwc_l1           : out (+)= mean |a - b| (losses.py:72), ws >= 1024 floats
+ *   gd_nhwc_l1_grad      : g = (*upstream) / n * sign(a - b), optionally gated by a > 0
+ * ---------------------------------------------------------------------------------------- */
+int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int transposed, void* ws, size_t ws_bytes, void* stream);
+int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bias, const void* mask, const void* res, void* y, int B,
+                    int H, int W, int K, int M, int relu, void* stream);
+int gd_nhwc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co, int relu,
+                     void* y, void* stream);
+int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream);
+int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, void* stream);
+int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx, void* stream);
+int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, void* stream);
+int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * PAM, fused (flash) form in bf16 with fp32 softmax statistics (generator.py:115-122).
  *   qt     : (B, Npad, 32) bf16, d zero-padded to 32, values PRE-SCALED by log2(e)  (gd_pack_bf16 scale_imm):
  *            the kernels work in the log2 domain and feed the softmax shift in as the MFMA accumulator input

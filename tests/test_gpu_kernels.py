@@ -365,3 +365,67 @@ def test_conv1x1_transpose_read_kernel(gd, shape):
     assert_close(yp, F.relu(F.conv2d(xin, w.cpu(), bias.cpu())), BF16_TOL, "1x1 fwd prologue")
     assert_close(dx, torch.nn.grad.conv2d_input((B, Cin, H, W), w.cpu(), dy.cpu()), BF16_TOL, "1x1 dgrad", rell2)
     assert_close(dw, torch.nn.grad.conv2d_weight(x.cpu(), (Cout, Cin, 1, 1), dy.cpu()), BF16_TOL, "1x1 wgrad", rell2)
+
+
+# ---- pixel-major bf16 kernels of the VGG feature stack -------------------------------------------------------------
+def _nhwc(t):      # (B, C, H, W) fp32 cpu -> (B, H, W, C) bf16 gpu
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def _nchw(t):      # (B, H, W, C) bf16 gpu -> (B, C, H, W) fp32 cpu
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32, 64), (1, 128, 17, 35, 256), (2, 40, 9, 70, 24), (1, 256, 8, 8, 512)])
+def test_conv3x3_nhwc_forward_and_data_gradient(gd, shape):
+    """gd_conv3x3_nhwc: forward (+bias+ReLU) and the data-gradient operator (ReLU mask and residual fused) against
+    ATen on the same bf16-rounded operands; results are bf16-rounded on store (tolerance = one bf16 ulp + the
+    usual accumulation-order slack)"""
+    _, K = _ops()
+    B, Cin, H, W, Cout = shape
+    x = bf16_round(seeded((B, Cin, H, W), 131))
+    w = bf16_round(seeded((Cout, Cin, 3, 3), 132, 1.0 / math.sqrt(Cin * 9)))
+    bias = seeded((Cout,), 133, 0.1)
+    y = K.conv3x3_nhwc(_nhwc(x), K.conv3x3_nhwc_pack(w.to(DEV), False), bias.to(DEV), Cout, relu=True)
+    yr = F.relu(F.conv2d(x, w, bias, padding=1))
+    assert_close(_nchw(y), yr, 1e-2, "nhwc fwd")
+    dy = bf16_round(seeded((B, Cout, H, W), 134))
+    act = bf16_round(seeded((B, Cin, H, W), 135))           # stands for the ReLU output feeding this conv
+    res = bf16_round(seeded((B, Cin, H, W), 136, 0.1))
+    dx = K.conv3x3_nhwc(_nhwc(dy), K.conv3x3_nhwc_pack(w.to(DEV), True), None, Cin, mask=_nhwc(act), res=_nhwc(res))
+    dxr = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, padding=1) * (act > 0).float() + res
+    assert_close(_nchw(dx), dxr, 1e-2, "nhwc dgrad with mask + res")
+
+
+@pytest.mark.parametrize("ci", [1, 3])
+def test_nhwc_stem_pool_l1(gd, ci):
+    _, K = _ops()
+    B, H, W, Co = 2, 24, 40, 64
+    img = seeded((B, ci, H, W), 141)
+    w = seeded((Co, ci, 3, 3), 142, 0.3)
+    bias = seeded((Co,), 143, 0.1)
+    a = K.nhwc_stem_fwd(img.to(DEV), w.to(DEV), bias.to(DEV), True)
+    ar = F.relu(F.conv2d(img, w, bias, padding=1))
+    assert_close(_nchw(a), ar, 1e-2, "stem fwd")
+    g = bf16_round(seeded((B, Co, H, W), 144))
+    dimg = K.nhwc_stem_bwd(_nhwc(g), w.to(DEV))
+    assert_close(dimg, torch.nn.grad.conv2d_input((B, ci, H, W), w, g, padding=1), 1e-4, "stem bwd")
+    # pooling on the (exactly representable) bf16 activations: forward exact, backward exact incl. the ReLU gate
+    av = _nchw(a).requires_grad_(True)
+    p = K.nhwc_maxpool2_fwd(a)
+    pr = F.max_pool2d(av, 2)
+    assert torch.equal(_nchw(p), pr.detach())
+    gp = bf16_round(seeded(tuple(pr.shape), 145))
+    pr.backward(gp)
+    dpx = K.nhwc_maxpool2_bwd(a, _nhwc(gp), True)
+    assert torch.equal(_nchw(dpx), av.grad * (av.detach() > 0).float())
+    # L1 distance and its gated gradient
+    b2 = K.nhwc_stem_fwd(seeded((B, ci, H, W), 146).to(DEV), w.to(DEV), bias.to(DEV), True)
+    out = torch.zeros(1, device=DEV)
+    K.nhwc_l1(a, b2, out, False)
+    fa, fb = _nchw(a), _nchw(b2)
+    assert_close(out, (fa - fb).abs().mean().view(1), 1e-5, "l1 value")
+    up = torch.full((1,), 0.5, device=DEV)
+    gl = K.nhwc_l1_grad(a, b2, up, True)
+    ref = 0.5 / fa.numel() * torch.sign(fa - fb) * (fa > 0).float()
+    assert_close(_nchw(gl), ref, 1e-2, "l1 grad")
