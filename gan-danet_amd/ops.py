@@ -295,8 +295,9 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
     return (*grads, dgamma_p)
 
 
-def _cam_forward(x, gamma_c, out3):
-    """CAM into ``out3``; always fp32 MFMA: the logits scale with N, bf16 operands would scramble the softmax."""
+def _cam_forward(x, gamma_c, out3, prec=L.PREC_FP32):
+    """CAM into ``out3``.  The Gram matrix / logits are always fp32 MFMA (they scale with N: bf16 operands would
+    scramble the softmax); ``prec`` is the operand type of the attention *apply* product only."""
     B, Cn, H, W = x.shape
     N = H * W
     x3 = x.view(B, Cn, N)
@@ -306,11 +307,11 @@ def _cam_forward(x, gamma_c, out3):
     att = K.softmax_rows(e, -1.0, out=e)   # softmax(rowmax(E) - E) == softmax(-E)
     K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=att,
               a_bs=Cn * Cn, a_sm=Cn, a_sc=1, a_st=0, x=x3, x_bs=Cn * N, y=out3, y_bs=K._bview(out3),
-              precision=L.PREC_FP32, alpha=gamma_c, res=x3, res_bs=Cn * N)
+              precision=prec, alpha=gamma_c, res=x3, res_bs=Cn * N)
     return att
 
 
-def _cam_backward(att, x, gamma_c, d_cam, dx):
+def _cam_backward(att, x, gamma_c, d_cam, dx, prec=L.PREC_FP32):
     """accumulates gamma * (att^T dOut + (dE + dE^T) X) into dx (residual added by the caller); returns dgamma"""
     B, Cn, H, W = x.shape
     N = H * W
@@ -324,10 +325,10 @@ def _cam_backward(att, x, gamma_c, d_cam, dx):
     sym = K.add_transpose(de)
     K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=att,
               a_bs=Cn * Cn, a_sm=1, a_sc=Cn, a_st=0, x=d_cam, x_bs=d_bs, y=dx, y_bs=Cn * N,
-              precision=L.PREC_FP32, alpha=gamma_c, accumulate=True)
+              precision=prec, alpha=gamma_c, accumulate=True)
     K.conv_nn(B=B, M=Cn, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=sym,
               a_bs=Cn * Cn, a_sm=Cn, a_sc=1, a_st=0, x=x3, x_bs=Cn * N, y=dx, y_bs=Cn * N,
-              precision=L.PREC_FP32, alpha=gamma_c, accumulate=True)
+              precision=prec, alpha=gamma_c, accumulate=True)
     return dgamma_c
 
 
@@ -363,7 +364,8 @@ class CamFn(Function):
     def forward(ctx, x, gamma_c):
         x = _c(x)
         out = torch.empty_like(x)
-        att = _cam_forward(x, gamma_c, _as3(out))
+        ctx.prec = _prec()
+        att = _cam_forward(x, gamma_c, _as3(out), ctx.prec)
         ctx.save_for_backward(x, gamma_c, att)
         return out
 
@@ -374,7 +376,7 @@ class CamFn(Function):
         d3 = _as3(_c(dout))
         dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
         K.copy_slab(d3, dx)
-        dg = _cam_backward(att, x, gamma_c, d3, dx)
+        dg = _cam_backward(att, x, gamma_c, d3, dx, ctx.prec)
         return dx.view(B, Cn, H, W), dg
 
 
@@ -389,7 +391,7 @@ class DualAttentionFn(Function):
         prec = _prec()
         feats = torch.empty(B, 2 * Cn, H, W, device=x.device, dtype=torch.float32)
         fused, saved = _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, _as3(feats[:, :Cn]), prec)
-        att = _cam_forward(x, gamma_c, _as3(feats[:, Cn:]))
+        att = _cam_forward(x, gamma_c, _as3(feats[:, Cn:]), prec)
         ctx.save_for_backward(x, wq, wk, wv, gamma_p, gamma_c, att, *saved)
         ctx.cfg = (prec, fused, (bq is not None, bk is not None, bv is not None))
         return feats
@@ -404,7 +406,7 @@ class DualAttentionFn(Function):
         dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
         K.copy_slab(d_pam, dx)                     # residual path of PAM
         K.copy_slab(d_cam, dx, accumulate=True)    # residual path of CAM
-        dgc = _cam_backward(att, x, gamma_c, d_cam, dx)
+        dgc = _cam_backward(att, x, gamma_c, d_cam, dx, prec)
         dwq, dbq, dwk, dbk, dwv, dbv, dgp = _pam_backward(fused, saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has_bias)
         return dx.view(B, Cn, H, W), dwq, dbq, dwk, dbk, dwv, dbv, dgp, dgc
 
