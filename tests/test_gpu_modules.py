@@ -473,3 +473,32 @@ def test_trainer_step_from_batch_with_input_gate(gd):
     assert abs(float(out.loss_g) - ro.loss_g) <= 1e-3 * max(1.0, abs(ro.loss_g))
     assert_close(A.fc2.weight, Ao.fc2.weight, 1e-3, "gate weights after the step", rell2)
     assert_close(G.final.weight, Go.final.weight, 1e-3, "G.final after the step", rell2)
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 45, 22), (1, 8, 88, 60)])
+def test_generator_eval_forward_inference_tiles_vs_oracle(gd, shape):
+    """f3 (the inference consumer, test.ipynb c1:123-146): eval-mode generator forward on the odd tile sizes the
+    test notebook feeds (45 x 22: N = 990 attention tokens, padded keys / ragged conv tiles everywhere) with
+    non-trivial running statistics, both precisions, against the CPU oracle"""
+    from oracle import modules as OM
+    Go = OM.FlexibleUpsamplingModule(input_channels=shape[1])
+    fill_module(Go)
+    gen = torch.Generator().manual_seed(17)
+    for mod in Go.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=gen) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=gen) * 0.5 + 0.75)
+    Go.eval()
+    G = gd.FlexibleUpsamplingModule(input_channels=shape[1])
+    G.load_state_dict(Go.state_dict())
+    G.to(DEV).eval()
+    x = bf16_round(seeded(shape, 151))
+    with torch.no_grad():
+        yo = Go(x)
+        with gd.precision("fp32"):
+            y32 = G(x.to(DEV))
+        with gd.precision("bf16"):
+            y16 = G(x.to(DEV))
+    assert tuple(y32.shape) == (shape[0], 1, 4 * shape[2], 4 * shape[3])
+    assert_close(y32, yo, 1e-3, "eval forward fp32")
+    assert_close(y16, yo, 5e-2, "eval forward bf16", rell2)
