@@ -183,6 +183,34 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     }
 }
 
+// ---- CustomDataset.apply_augmentation (datasets.py:181-208) as one gather -------------------------------------------
+// op word of a sample: bit 0 horizontal flip, bit 1 vertical flip, bits 2-3 number of 90-degree turns (torch.rot90,
+// dims [1, 2]), bit 4 additive noise.  The three geometric steps compose to one index map; tiles are square when
+// the number of turns is odd.  dst[b][c][y][x] = src[b][c][sy][sx] (+ scale * noise[b][c][y][x])
+__global__ void augment_d4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
+                                  const int* __restrict__ ops, const float* __restrict__ noise, float scale, long total) {
+#pragma clang fp contract(off)      // x + noise * 0.05 stays a rounded multiply and a rounded add, like the reference
+    const long plane = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long bc = i / plane;
+        const int rem = (int)(i - bc * plane);
+        const int op = ops[bc / C];
+        const int k = (op >> 2) & 3;
+        // output geometry: (H, W) turns into (W, H) for odd k; square tiles keep the strides simple
+        const int y = rem / W, x = rem - y * W;
+        int ry, rx;                                   // source of the rotation: R1[i][j] = M[j][n-1-i], ...
+        if (k == 0) { ry = y; rx = x; }
+        else if (k == 1) { ry = x; rx = W - 1 - y; }
+        else if (k == 2) { ry = H - 1 - y; rx = W - 1 - x; }
+        else { ry = H - 1 - x; rx = y; }
+        if (op & 2) ry = H - 1 - ry;                  // undo the vertical flip (applied before the rotation)
+        if (op & 1) rx = W - 1 - rx;                  // undo the horizontal flip (applied first)
+        float v = src[bc * plane + (long)ry * W + rx];
+        if (noise && (op & 16)) v = v + scale * noise[i];
+        dst[i] = v;
+    }
+}
+
 // ---- attention gates of SqueezeExcitation / CBAMBlock (generator.py:70-101) ------------------------------------
 // y[b][c][p] = x[b][c][p] * att ; mode 0: att[b][c] (channel gate), mode 1: att[b][p] (spatial gate)
 __global__ void bcast_mul_kernel(const float* __restrict__ x, const float* __restrict__ att, float* __restrict__ y, int C,
@@ -461,6 +489,15 @@ extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, con
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
                        scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
                        ld_t, perm16, ones_row);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_augment_d4(const float* src, float* dst, int B, int C, int H, int W, const int* ops, const float* noise,
+                             float noise_scale, void* stream) {
+    GD_CHECK_ARG(src && dst && ops && src != dst && B > 0 && C > 0 && H > 0 && W > 0, "gd_augment_d4: bad arguments");
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(augment_d4_kernel, dim3(grid_for(total)), dim3(256), 0, GD_S, src, dst, C, H, W, ops, noise,
+                       noise_scale, total);
     GD_LAUNCH_CHECK();
     return 0;
 }

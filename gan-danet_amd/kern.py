@@ -534,6 +534,19 @@ def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, sca
     return plain, tr
 
 
+def augment_d4(x: Tensor, ops: Tensor, noise: Optional[Tensor] = None, noise_scale: float = 0.05) -> Tensor:
+    """per-sample flip / flip / rot90 (+ noise) of a (B, C, H, W) batch; ``ops`` int32 (B,) op words (gandanet.h)"""
+    _dense(x, "augment input")
+    _chk(ops, "augment ops", torch.int32)
+    B, Cn, H, W = x.shape
+    if ops.numel() != B or (noise is not None and _dense(noise, "noise").shape != x.shape):
+        raise L.GandanetError("augment_d4: ops must hold one word per sample and noise must match the batch")
+    y = torch.empty_like(x)
+    L.check(lib().gd_augment_d4(_ptr(x), _ptr(y), B, Cn, H, W, _ptr(ops), _ptr(noise), float(noise_scale), _stream()),
+            "gd_augment_d4")
+    return y
+
+
 def bcast_mul(x: Tensor, att: Tensor, mode: int) -> Tensor:
     """x (B, C, H, W) dense times a channel gate att (B, C) [mode 0] or a spatial gate att (B, H*W) [mode 1]"""
     _dense(x), _dense(att)

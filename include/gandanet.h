@@ -265,6 +265,12 @@ int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn, float* dkn,
                      float* dv, void* stream);
+/* CustomDataset.apply_augmentation (datasets.py:181-208) for a batch of tiles as one gather: per-sample op word
+ * ops[b] = hflip | vflip << 1 | quarter_turns << 2 | noise << 4 (flip W, flip H, torch.rot90 k, in that order; H == W
+ * when a sample is turned an odd number of times -- checked by the host).  noise (same shape as dst) may be NULL;
+ * it is added times noise_scale (0.05 in the reference) to the samples whose noise bit is set.  src != dst. */
+int gd_augment_d4(const float* src, float* dst, int B, int C, int H, int W, const int* ops, const float* noise,
+                  float noise_scale, void* stream);
 /* attention gates of SqueezeExcitation / CBAMBlock (generator.py:70-101; exported by the reference, not on the
  * train path).  Dense (B, C, HW) fp32.
  *   gd_bcast_mul       : y = x * att; mode 0: att (B, C) channel gate (generator.py:84), mode 1: att (B, HW)
