@@ -293,11 +293,17 @@ __device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld
     return f;
 }
 
-template <int CT>
+// DQ: also emit this key block's contribution to dQ.  dS is already in registers here; recomputing S and dP in a
+// second query-parallel kernel (pam_bwd_dq_kernel) costs 14 MFMAs per 32x32 tile, turning the tile around through
+// 2.5 KB of wave-private LDS and 2 more MFMAs does not: each wave transposes its dS tile (LDS transpose read),
+// multiplies by its K rows, the four waves' partial dQ^T tiles are summed after the barrier and stored as bf16
+// [key block][query][32 d]; pam_dq_reduce_kernel sums the key blocks.  No atomics: deterministic.
+template <int CT, bool DQ>
 __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
-    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ vt,
-    const unsigned short* __restrict__ dot_, const float* __restrict__ lse, const float* __restrict__ delta, int N,
-    int Npad, float* __restrict__ dkn, float* __restrict__ dv) {
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
+    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ lse,
+    const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn, float* __restrict__ dv,
+    unsigned short* __restrict__ dq_part) {
     constexpr int CP = CT * 32;
     constexpr int NT = 256;
     constexpr int DLD = CP + 8;
@@ -308,6 +314,8 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
     __shared__ float Ls[32], Ds[32];
+    constexpr int XLD = 40;                                      // 80-byte rows: conflict-light 8-byte accesses
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[DQ ? 4 * 32 * XLD : 8];   // per wave: dS^T, then its dQ^T part
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -318,6 +326,16 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
     bf16x8_t kfB[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) kfB[s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + r) * 32 + s * 16 + 8 * h);
+    // K^T rows of this wave's keys as the A operand of dQ^T[d][i] += K^T[d][j] dS^T[j][i]: lane = d, 8 keys per k-step
+    // (kn is stored perm16: one 16-byte read is an accumulator-row-ordered k-step)
+    bf16x8_t knA[2];
+    if (DQ) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            knA[s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + s * 16 + 8 * h);
+    }
+    unsigned short* Xw = Xs + (DQ ? wave * 32 * XLD : 0);
+    unsigned short* part = DQ ? dq_part + ((long)b * (Npad / 128) + blockIdx.x) * Npad * 32 : nullptr;
     {
         const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * 128) * CP;
         for (int c = tid; c < 128 * (CP / 8); c += NT) {
@@ -339,32 +357,39 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
     const bool need_mask = (int)(blockIdx.x + 1) * 128 > N;
     const int nqt = (N + 31) / 32;
 
-    // staging plan (fixed per thread): source at tile 0, elements per tile, LDS slot
-    const unsigned short* src[NPRE];
-    int step[NPRE];
-    unsigned short* dst[NPRE];
+    // staging plan: 32-bit element offset inside the tile's Q or dO source and LDS slot.  Chunks 0..127 are Q, i.e.
+    // exactly waves 0-1 of round k = 0: the source kind of a (round, wave) is wave-uniform, so the 64-bit base stays
+    // in SGPRs
+    // (packed two to a register: at CT = 6 the kernel sits on the 256-VGPR line)
+    unsigned int plan[NPRE];
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
         int c = tid + k * NT;
-        if (RAGGED && k == NPRE - 1 && c >= NCHUNK) c = 0;
+        if (RAGGED && k == NPRE - 1 && c >= NCHUNK) c = 128;
+        unsigned int so, dof;
         if (c < 128) {
-            src[k] = qt + (nb + (c >> 2)) * 32 + (c & 3) * 8;  step[k] = 32 * 32;
-            dst[k] = Qs + (c >> 2) * B_QLD + (c & 3) * 8;
+            so = (unsigned int)((c >> 2) * 32 + (c & 3) * 8);
+            dof = (unsigned int)((c >> 2) * B_QLD + (c & 3) * 8);
         } else {
             const int c2 = c - 128;
             const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
-            src[k] = dot_ + (nb + i) * CP + ch * 8;  step[k] = 32 * CP;
-            dst[k] = dOs + i * DLD + ch * 8;
+            so = (unsigned int)(i * CP + ch * 8);
+            dof = (unsigned int)(i * DLD + ch * 8);
         }
+        plan[k] = so | (dof << 16);          // both < 32 * 200
     }
     const bool last_ok = !RAGGED || (tid + (NPRE - 1) * NT) < NCHUNK;
+    const bool q_round0 = __builtin_amdgcn_readfirstlane(tid < 128 ? 1 : 0) != 0;
 
     u32x4_t pre[NPRE];
     float pre_s = 0.f;
     auto load_tile = [&](int qtile) {
+        const unsigned short* qbase = qt + (nb + (long)qtile * 32) * 32;
+        const unsigned short* dbase = dot_ + (nb + (long)qtile * 32) * CP;
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k)
-            pre[k] = *reinterpret_cast<const u32x4_t*>(src[k] + (long)qtile * step[k]);
+        for (int k = 0; k < NPRE; ++k) {
+            pre[k] = *reinterpret_cast<const u32x4_t*>((k == 0 && q_round0 ? qbase : dbase) + (plan[k] & 0xFFFFu));
+        }
         if (tid < 64) {
             const int i = qtile * 32 + (tid & 31);
             pre_s = i < N ? -(tid < 32 ? lse[(long)b * N + i] * LOG2E : delta[(long)b * N + i]) : 0.f;
@@ -373,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
     auto store_tile = [&]() {
 #pragma unroll
         for (int k = 0; k < NPRE; ++k)
-            if (k < NPRE - 1 || last_ok) *reinterpret_cast<u32x4_t*>(dst[k]) = pre[k];
+            if (k < NPRE - 1 || last_ok)
+                *reinterpret_cast<u32x4_t*>((k == 0 && q_round0 ? Qs : dOs) + (plan[k] >> 16)) = pre[k];
         if (tid < 32) Ls[tid] = pre_s;
         else if (tid < 64) Ds[tid - 32] = pre_s;
     };
@@ -418,17 +444,59 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
             pf[s] = pack_frag(sacc, s);
             dsf[s] = pack_frag(dpacc, s);
         }
+        // the dS tile takes a round trip through wave-private LDS (transpose) for dQ; it is written before the dV^T
+        // MFMAs and read back after them, so the trip is covered by matrix work
+        if (DQ) {
+            // dS tile [query rows][key lanes] -> X[key][query] (this lane's 16 queries are 4 runs of 4)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4_t w = __builtin_bit_cast(u32x4_t, dsf[s]);
+                const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
+                *reinterpret_cast<u32x2_t*>(Xw + r * XLD + 16 * s + 4 * h) = lo;
+                *reinterpret_cast<u32x2_t*>(Xw + r * XLD + 16 * s + 8 + 4 * h) = hi;
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_tr_frag(dOs, DLD, s, ct * 32, lane), pf[s], dvacc[ct]);
+        f32x16_t dqp;
+        if (DQ) {
+            // transpose read = the B operand (lane = query, k = key) of dQ^T[d][i] += K^T[d][j] dS^T[j][i]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dqp[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dqp = mfma_bf16(knA[s], read_tr_frag(Xw, XLD, s, 0, lane), dqp);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) dkacc = mfma_bf16(read_tr_frag(Qs, B_QLD, s, 0, lane), dsf[s], dkacc);
-        __syncthreads();
-        if (qtile + 1 < nqt) {
-            store_tile();
-            __syncthreads();
+        if (DQ) {
+            // dQ^T part [d rows][query lanes] -> P[query][d] over the same wave-private region
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4_t w = __builtin_bit_cast(u32x4_t, pack_frag(dqp, s));
+                const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
+                *reinterpret_cast<u32x2_t*>(Xw + r * XLD + 16 * s + 4 * h) = lo;
+                *reinterpret_cast<u32x2_t*>(Xw + r * XLD + 16 * s + 8 + 4 * h) = hi;
+            }
         }
+        __syncthreads();
+        if (DQ) {   // sum the four waves' parts: thread = (query, 4 d) ; 2 KiB contiguous per key block and query tile
+            const int q = tid >> 3, dg = (tid & 7) * 4;
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const u32x2_t v2 = *reinterpret_cast<const u32x2_t*>(Xs + w4 * 32 * XLD + q * XLD + dg);
+                acc4[0] += gd_bf2f((unsigned short)(v2.x & 0xFFFFu));
+                acc4[1] += gd_bf2f((unsigned short)(v2.x >> 16));
+                acc4[2] += gd_bf2f((unsigned short)(v2.y & 0xFFFFu));
+                acc4[3] += gd_bf2f((unsigned short)(v2.y >> 16));
+            }
+            const u32x2_t o = {gd_pack_bf2(acc4[0], acc4[1]), gd_pack_bf2(acc4[2], acc4[3])};
+            *reinterpret_cast<u32x2_t*>(part + ((long)i0 + q) * 32 + dg) = o;
+        }
+        if (qtile + 1 < nqt) store_tile();
+        if (DQ || qtile + 1 < nqt) __syncthreads();
     }
 
     const int j = j0 + r;
@@ -438,6 +506,36 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
         for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[ct][e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[e] * LN2;   // Q^T was q * log2 e
+}
+
+// dQ^T[b][d][i] = sum over key blocks of the bf16 parts written by pam_bwd_dkv3_kernel<CT, true>
+//   part : (B, KB, Npad, 32) bf16 ; dqn : (B, 32, Npad) fp32.  One workgroup = 64 queries of one image; a key block's
+//   slab for them is 4 KiB contiguous (thread = query x 8 d, 16-byte loads).
+__global__ __launch_bounds__(256) void pam_dq_reduce_kernel(const unsigned short* __restrict__ part, int KB, int Npad,
+                                                           float* __restrict__ dqn) {
+    __shared__ float tile[32][65];
+    const int b = blockIdx.y, i0 = blockIdx.x * 64;
+    const int q = threadIdx.x >> 2, d8 = (threadIdx.x & 3) * 8;
+    const unsigned short* p = part + ((long)b * KB * Npad + i0 + q) * 32 + d8;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll 4
+    for (int kb = 0; kb < KB; ++kb) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p + (long)kb * Npad * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += gd_bf2f((unsigned short)(v[k] & 0xFFFFu));
+            acc[2 * k + 1] += gd_bf2f((unsigned short)(v[k] >> 16));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[d8 + k][q] = acc[k];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
+        const int d = idx >> 6, qq = idx & 63;
+        dqn[((long)b * 32 + d) * Npad + i0 + qq] = tile[d][qq];
+    }
 }
 
 // =====================================================================================================
@@ -617,23 +715,40 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     return 0;
 }
 
+extern "C" size_t gd_pam_dq_part_bytes(int Npad) { return (size_t)(Npad / 128) * (size_t)Npad * 32 * sizeof(unsigned short); }
+
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                 const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn,
-                                float* dkn, float* dv, void* stream) {
+                                float* dkn, float* dv, void* dq_part, size_t dq_part_bytes, void* stream) {
     GD_CHECK_ARG(qt && kt && kn && vt && dot_ && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
     hipStream_t s = (hipStream_t)stream;
-    // dK / dV: transpose-read kernel, 4 waves (128 keys), two independent workgroups per CU
-    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT>), dim3(Npad / 128, B), dim3(256), 0, s,
-                                                 (const unsigned short*)qt, (const unsigned short*)kt,
-                                                 (const unsigned short*)vt, (const unsigned short*)dot_, lse, delta, N,
-                                                 Npad, dkn, dv));
-    // dQ: 8 waves (256 queries) per workgroup, 128-key LDS-DMA tiles; kn must be packed perm16 along the keys
-    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0, s,
-                                                 (const unsigned short*)qt, (const unsigned short*)kt,
-                                                 (const unsigned short*)kn, (const unsigned short*)vt,
-                                                 (const unsigned short*)dot_, lse, delta, N, Npad, dqn));
+    const unsigned short *q = (const unsigned short*)qt, *k = (const unsigned short*)kt, *kT = (const unsigned short*)kn;
+    const unsigned short *v = (const unsigned short*)vt, *dO = (const unsigned short*)dot_;
+    const size_t per_image = gd_pam_dq_part_bytes(Npad);
+    if (dq_part && dq_part_bytes >= per_image) {
+        // fused: the key-parallel kernel also emits bf16 dQ parts per key block, summed by a streaming kernel; the
+        // batch is walked in slices that fit the caller's scratch buffer
+        const int slice = (int)(dq_part_bytes / per_image < (size_t)B ? dq_part_bytes / per_image : (size_t)B);
+        for (int b0 = 0; b0 < B; b0 += slice) {
+            const int nb = B - b0 < slice ? B - b0 : slice;
+            const long o32 = (long)b0 * Npad * 32, oc = (long)b0 * Npad * Cp, on = (long)b0 * N;
+            PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true>), dim3(Npad / 128, nb), dim3(256), 0, s,
+                                                         q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
+                                                         N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
+            hipLaunchKernelGGL(pam_dq_reduce_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const unsigned short*)dq_part,
+                               Npad / 128, Npad, dqn + o32);
+        }
+        GD_LAUNCH_CHECK();
+        return 0;
+    }
+    // two-kernel form: dK / dV (transpose-read kernel, 4 waves = 128 keys, two workgroups per CU), then dQ with a
+    // query-parallel kernel that recomputes S and dP (8 waves, 128-key LDS-DMA tiles; kn perm16 along the keys)
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, false>), dim3(Npad / 128, B), dim3(256), 0, s, q, k,
+                                                 kT, v, dO, lse, delta, N, Npad, dkn, dv, (unsigned short*)nullptr));
+    PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dq_kernel<CT, 8, 128>), dim3(Npad / 256, B), dim3(512), 0, s, q, k,
+                                                 kT, v, dO, lse, delta, N, Npad, dqn));
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -603,11 +604,22 @@ def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_a
                 "gd_pam_flash_fwd")
 
 
+PAM_DQ_FUSED = os.environ.get("GD_PAM_DQ_FUSED", "1") != "0"      # 0: two-kernel backward (A/B reference, no scratch)
+PAM_DQ_PART_CAP = 32 << 30                                         # scratch for the dQ parts: at most 32 GiB per call
+
+
 def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0):
+    part, part_bytes = None, 0
+    if PAM_DQ_FUSED:
+        per_image = int(lib().gd_pam_dq_part_bytes(Npad))
+        images = max(1, min(B, PAM_DQ_PART_CAP // per_image))
+        part_bytes = per_image * images
+        part = torch.empty(part_bytes, device=dqn.device, dtype=torch.uint8)
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
         L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(lse), _ptr(delta), B,
-                                       N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv), _stream()), "gd_pam_flash_bwd")
+                                       N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv), _ptr(part), part_bytes, _stream()),
+                "gd_pam_flash_bwd")
 
 
 # =====================================================================================================

@@ -256,15 +256,20 @@ int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream,
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                      int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
                      float* o_attn, float* lse, void* stream);
-/* backward: bf16 inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care); vt (B,Npad,Cp);
- * dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
+/* backward: bf16 inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care);
+ * vt (B,Npad,Cp); dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
  * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad) -- gradients w.r.t. the
- * UNSCALED q, k, v.  Two launches: a key-parallel kernel for dK/dV (transposed operands are taken from qt / dot
- * with LDS transpose reads) and a query-parallel kernel for dQ (no atomics: bitwise reproducible).
- * Npad % 256 == 0. */
+ * UNSCALED q, k, v.  Npad % 256 == 0.  No atomics in either form: bitwise reproducible.
+ *   dq_part != NULL (caller-owned scratch of dq_part_bytes >= gd_pam_dq_part_bytes(Npad), i.e. one image's worth;
+ *     more lets more images go per launch): ONE key-parallel kernel computes dK, dV and, from the dS tiles it
+ *     already holds, bf16 dQ parts per 128-key block [key block][query][32]; a streaming kernel sums the blocks.
+ *   dq_part == NULL: the key-parallel kernel for dK/dV, then a query-parallel kernel that recomputes S and dP for dQ
+ *     (1.37x the matrix work, no scratch). */
+size_t gd_pam_dq_part_bytes(int Npad);
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn, float* dkn,
-                     float* dv, void* stream);
+                     float* dv, void* dq_part, size_t dq_part_bytes, void* stream);
+
 /* CustomDataset.apply_augmentation (datasets.py:181-208) for a batch of tiles as one gather: per-sample op word
  * ops[b] = hflip | vflip << 1 | quarter_turns << 2 | noise << 4 (flip W, flip H, torch.rot90 k, in that order; H == W
  * when a sample is turned an odd number of times -- checked by the host).  noise (same shape as dst) may be NULL;
