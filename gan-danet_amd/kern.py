@@ -605,14 +605,15 @@ def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_a
 
 
 PAM_DQ_FUSED = os.environ.get("GD_PAM_DQ_FUSED", "1") != "0"      # 0: two-kernel backward (A/B reference, no scratch)
-PAM_DQ_PART_CAP = 32 << 30                                         # scratch for the dQ parts: at most 32 GiB per call
+PAM_DQ_PART_CAP = 40 << 30                                         # scratch for the dQ parts: at most 40 GiB per call
 
 
 def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0):
     part, part_bytes = None, 0
     if PAM_DQ_FUSED:
         per_image = int(lib().gd_pam_dq_part_bytes(Npad))
-        images = max(1, min(B, PAM_DQ_PART_CAP // per_image))
+        nslices = -(-(B * per_image) // PAM_DQ_PART_CAP)              # even slices of the batch that fit the cap
+        images = max(1, -(-B // nslices))
         part_bytes = per_image * images
         part = torch.empty(part_bytes, device=dqn.device, dtype=torch.uint8)
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
