@@ -221,30 +221,21 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
             l += lsum;
         }
 
-        // V fragments are read in batches of FB ahead of the MFMAs that consume them (the scheduler is pinned with
-        // sched_group_barrier: FB LDS reads, then FB MFMAs), so one LDS round trip is paid per batch, not per MFMA
-        constexpr int FB = 8, NF = 2 * NSUB * CT;
+        // V fragments are read in batches ahead of the MFMAs that consume them (the scheduler is pinned with
+        // sched_group_barrier: CT LDS reads, then CT MFMAs), so one LDS round trip is paid per batch, not per MFMA.
+        // A batch is one k-step of all CT channel tiles: its MFMAs write CT different accumulators (no
+        // back-to-back dependent MFMAs on one accumulator)
 #pragma unroll
-        for (int f0 = 0; f0 < NF; f0 += FB) {
-            bf16x8_t vf[FB];
+        for (int ks = 0; ks < 2 * NSUB; ++ks) {
+            const int sub = ks >> 1, s2 = ks & 1;
+            bf16x8_t vf[CT];
 #pragma unroll
-            for (int i = 0; i < FB; ++i) {
-                const int f = f0 + i;
-                if (f < NF) {
-                    const int ct = f / (2 * NSUB), sub = (f >> 1) % NSUB, s2 = f & 1;
-                    vf[i] = *reinterpret_cast<const bf16x8_t*>(Vs + (ct * 32 + r) * VLD + sub * 32 + s2 * 16 + 8 * h);
-                }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, FB, 0);   // DS reads
+            for (int ct = 0; ct < CT; ++ct)
+                vf[ct] = *reinterpret_cast<const bf16x8_t*>(Vs + (ct * 32 + r) * VLD + sub * 32 + s2 * 16 + 8 * h);
+            __builtin_amdgcn_sched_group_barrier(0x100, CT, 0);   // DS reads
 #pragma unroll
-            for (int i = 0; i < FB; ++i) {
-                const int f = f0 + i;
-                if (f < NF) {
-                    const int ct = f / (2 * NSUB), sub = (f >> 1) % NSUB, s2 = f & 1;
-                    o[ct] = mfma_bf16(vf[i], pf[sub][s2], o[ct]);
-                }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, FB, 0);   // MFMAs
+            for (int ct = 0; ct < CT; ++ct) o[ct] = mfma_bf16(vf[ct], pf[sub][s2], o[ct]);
+            __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);   // MFMAs
         }
     }
 
