@@ -501,16 +501,20 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
-template <int NW, int S>
+// CS = false: the NW waves are NW output-channel tiles (BM = 32 NW) over ONE 32-channel chunk of ci.
+// CS = true (Cout <= 32, the 24-channel dense layers): the waves are NW ci-CHUNKS sharing one 32-row dY tile -- the
+//   dY tile is staged once for 32 NW input channels, no wave multiplies an all-zero m-tile, and the workgroup has
+//   NW x 64 threads to keep loads in flight (with waves = m-tiles a Cout of 24 left 128 threads per workgroup).
+template <int NW, int S, bool CS>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
-    constexpr int BM = 32 * NW, NT = 64 * NW;
+    constexpr int BM = CS ? 32 : 32 * NW, NT = 64 * NW, NCH = CS ? NW : 1;
     constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
     __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
-    __shared__ __attribute__((aligned(16))) unsigned short patch[NPIXk * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short patch[NCH * NPIXk * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int c0 = blockIdx.x * CK;
+    const int c0 = blockIdx.x * CK * NCH;
     const int m0 = blockIdx.y * BM;
     const long HW = (long)a.H * a.W;            // input plane
     const long HWo = (long)a.Ho * a.Wo;         // output (dY) plane
@@ -538,8 +542,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
         // ---- dY tile -> [co][pixel] bf16 : 4-pixel vectors, BM*32 of them ----
 #pragma unroll 4
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 16 / (CS ? NW : 1) + (CS && (16 % NW) ? 1 : 0); ++k) {
             const int idx = tid + k * NT;
+            if (CS && idx >= 32 * 32) break;
             const int m = idx >> 5, v = idx & 31;
             const int yy = y0 + (v >> 3), xx = x0 + (v & 7) * 4;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,15 +565,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
         }
         // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU): item = (patch pixel, channel half) ----
-        for (int w = tid; w < 2 * NPIXk; w += NT) {
-            const int half = w >= NPIXk ? 1 : 0;
-            const int pix = w - half * NPIXk;
+        for (int w = tid; w < 2 * NCH * NPIXk; w += NT) {
+            const int hc = w / NPIXk;                   // (chunk, channel half)
+            const int half = hc & 1, chk = hc >> 1;
+            const int pix = w - hc * NPIXk;
             const int py = pix / PWk, px = pix - py * PWk;
             const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
             const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const int cb = c0 + half * 16;
+            const int cb = c0 + chk * CK + half * 16;
             const float* p = xb + (long)cb * HW + (long)iy * a.W + ix;
-            unsigned int* dst = reinterpret_cast<unsigned int*>(patch + pix * LD + half * 16);
+            unsigned int* dst = reinterpret_cast<unsigned int*>(patch + (chk * NPIXk + pix) * LD + half * 16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = cb + 2 * j;
@@ -595,13 +601,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
         // ---- 8 k-steps of 16 pixels x 9 taps ----
 #pragma unroll 2
         for (int s = 0; s < 8; ++s) {
-            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(dys + (wave * 32 + r) * DYLD + 16 * s + 8 * h);
+            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(dys + ((CS ? 0 : wave * 32) + r) * DYLD + 16 * s + 8 * h);
             const int prow = s >> 1, pcol = (s & 1) * 16 + 8 * h + tq;   // tile-local OUTPUT pixel of this lane's block row
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const unsigned short* p0 = patch + ((prow * S + ky) * PWk + pcol * S + kx) * LD + 16 * tg + 4 * tp;
+                    const unsigned short* p0 = patch + ((CS ? wave * NPIXk : 0) + (prow * S + ky) * PWk + pcol * S + kx) * LD +
+                                               16 * tg + 4 * tp;
                     const s16x4_t lo = lds_tr_read(p0);                // output pixels +0..3
                     const s16x4_t hi = lds_tr_read(p0 + 4 * S * LD);   // output pixels +4..7
                     const bf16x8_t fb = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -614,13 +621,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
     }
 
     // ---- combine: dW[co][ci][tap] += acc ----
-    const int ci = c0 + r;
+    const int ci = c0 + (CS ? wave * CK : 0) + r;
     if (ci < a.Ck) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = m0 + wave * 32 + acc_row(e, h);
+                const int co = m0 + (CS ? 0 : wave * 32) + acc_row(e, h);
                 if (co < a.M) atomicAdd(a.dw + ((long)co * a.Ck + ci) * 9 + t, acc[t][e]);
             }
     }
@@ -654,23 +661,32 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, lon
         const long bm = 32L * nw, pad = ((Cout + bm - 1) / bm) * bm;
         if (best_pad < 0 || pad <= best_pad) { best_pad = pad; best_nw = nw; }
     }
-    const int bm = 32 * best_nw;
-    const int mblocks = (Cout + bm - 1) / bm, chunks = (Cin + CK - 1) / CK;
-    long splits = 1024 / ((long)mblocks * chunks);
+    const int chunks = (Cin + CK - 1) / CK;
+    // Cout <= 32 at stride 1: waves = ci chunks (3..4 per workgroup, spread evenly over the groups).  With only two
+    // chunks it is slower than two independent 2-wave workgroups (9.2 vs 5 ms on the 64 -> 1 conv at 1024 x 1024).
+    const bool cs = Cout <= 32 && stride == 1 && chunks >= 3;
+    const int groups = cs ? (chunks + 3) / 4 : chunks;
+    const int cs_nw = cs ? (chunks + groups - 1) / groups : 0;
+    const int bm = cs ? 32 : 32 * best_nw;
+    const int mblocks = (Cout + bm - 1) / bm;
+    long splits = 1024 / ((long)mblocks * groups);
     if (splits < 1) splits = 1;
     if (splits > ntiles) splits = ntiles;
     if (splits > 65535) splits = 65535;
     a.tiles_per_split = (int)((ntiles + splits - 1) / splits);
     splits = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
-    dim3 grid(chunks, mblocks, (unsigned)splits);
-    if (stride == 1) {
-        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1>), grid, dim3(128), 0, s, a);
-        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 1>), grid, dim3(384), 0, s, a);
+    dim3 grid(groups, mblocks, (unsigned)splits);
+    if (cs) {
+        if (cs_nw == 3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<3, 1, true>), grid, dim3(192), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, true>), grid, dim3(256), 0, s, a);
+    } else if (stride == 1) {
+        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1, false>), grid, dim3(128), 0, s, a);
+        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 1, false>), grid, dim3(384), 0, s, a);
     } else {
-        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 2>), grid, dim3(128), 0, s, a);
-        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 2>), grid, dim3(384), 0, s, a);
+        if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 2, false>), grid, dim3(128), 0, s, a);
+        else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 2, false>), grid, dim3(384), 0, s, a);
     }
     GD_LAUNCH_CHECK();
     return 0;

@@ -279,7 +279,9 @@ def test_transpose_and_pack(gd):
     assert torch.equal(tr.float().cpu(), ref.transpose(1, 2).to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("shape", [(2, 72, 24, 64, 184), (1, 368, 16, 32, 184), (1, 64, 40, 96, 64), (2, 3, 33, 70, 64)])
+@pytest.mark.parametrize("shape", [(2, 72, 24, 64, 184), (1, 368, 16, 32, 184), (1, 64, 40, 96, 64), (2, 3, 33, 70, 64),
+                                   # Cout <= 32 (dense layers): weight gradient with waves = ci chunks (2, 4, 3+2, 3)
+                                   (2, 64, 16, 32, 24), (1, 112, 9, 40, 24), (1, 160, 8, 32, 24), (1, 88, 8, 64, 32)])
 def test_conv3x3_patch_kernel_matches_generic_and_oracle(gd, shape):
     """the LDS-patch 3x3 kernel against the generic implicit-GEMM kernel (same bf16 operands -> agreement to
     fp32 accumulation order) and against the oracle; forward with fused BN-affine+ReLU prologue, bias, ReLU,
