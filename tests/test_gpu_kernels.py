@@ -128,7 +128,7 @@ def test_batchnorm_act(gd, shape, train):
     assert_close(rvg, bn.running_var, 1e-5, "running_var")
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 2, 45, 22), (2, 4, 16, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 2, 45, 22), (2, 4, 16, 32), (1, 2, 40, 100), (2, 1, 27, 131)])
 def test_bicubic_up2(gd, shape):
     ops, _ = _ops()
     x = seeded(shape, 21)
@@ -153,7 +153,8 @@ def test_bicubic_downscale_forward(gd):
         assert_close(y, yr, 1e-5, f"bicubic x{sf}")
 
 
-@pytest.mark.parametrize("shape,out", [((2, 3, 8, 8), (32, 32)), ((1, 2, 45, 22), (180, 88)), ((1, 2, 7, 9), (14, 27))])
+@pytest.mark.parametrize("shape,out", [((2, 3, 8, 8), (32, 32)), ((1, 2, 45, 22), (180, 88)), ((1, 2, 7, 9), (14, 27)),
+                                       ((1, 2, 40, 100), (160, 400)), ((2, 1, 27, 131), (108, 524))])
 def test_bilinear(gd, shape, out):
     ops, _ = _ops()
     x = seeded(shape, 24)
