@@ -94,6 +94,40 @@ __global__ __launch_bounds__(256) void combine_inputs_kernel(const float* __rest
     out[((long)z * Ho + oy) * Wo + ox] = acc;
 }
 
+// Tail of the generator (generator.py:242-247): final = conv3x3(64 -> 1, pad 1) applied to up2(c) + resize4(s) is linear
+// in c and s and the resizes act per channel, so  final(z)[p] = b + sum_tap u_tap[p + off_tap]  with the nine "tap planes"
+// u_tap = up2(sum_ch w[ch][tap] c_ch) + resize4(sum_ch w[ch][tap] s_ch): the channel contraction runs at LOW resolution and
+// only 9 planes (not 64 channels) exist at 4H x 4W.  This kernel is the last step: shifted sum of the planes (+ bias).
+__global__ __launch_bounds__(256) void shift_sum9_fwd_kernel(const float* __restrict__ u, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int H, int W) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    const long b = blockIdx.z;
+    if (x >= W) return;
+    const long HW = (long)H * W;
+    const float* ub = u + b * 9 * HW;
+    float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sy = yy + t / 3 - 1, sx = x + t % 3 - 1;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc += ub[t * HW + (long)sy * W + sx];
+    }
+    y[b * HW + (long)yy * W + x] = acc;
+}
+// du[b][tap][q] = dy[b][q - off_tap] (zero outside the image)
+__global__ __launch_bounds__(256) void shift_sum9_bwd_kernel(const float* __restrict__ dy, float* __restrict__ du, int H, int W) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y;
+    const long b = blockIdx.z;
+    if (x >= W) return;
+    const long HW = (long)H * W;
+    const float* g = dy + b * HW;
+    float* ub = du + b * 9 * HW;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sy = yy - (t / 3 - 1), sx = x - (t % 3 - 1);
+        ub[t * HW + (long)yy * W + x] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? g[(long)sy * W + sx] : 0.f;
+    }
+}
+
 // conservative window of output coordinates that may read input coordinate i (cubic: |src - i| < 2 + clamp)
 __device__ __forceinline__ void cubic_window(int i, float rs, int n_in, int n_out, int& lo, int& hi) {
     const float inv = 1.f / rs;
@@ -349,6 +383,19 @@ extern "C" int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, 
     GD_FOR_BC_SLICES(BC, hipLaunchKernelGGL(bicubic_fwd_kernel, dim3(gd_cdiv(Wo, 256), Ho, nz_), dim3(256), 0,
                                             (hipStream_t)stream, x + z0_ * (long)Hi * Wi, Hi, Wi,
                                             y + z0_ * (long)Ho * Wo, Ho, Wo, rsh, rsw);)
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_shift_sum9_fwd(const float* u, const float* bias, float* y, int B, int H, int W, void* stream) {
+    GD_CHECK_ARG(u && y && B > 0 && B <= 65535 && H > 0 && H <= 65535 && W > 0, "gd_shift_sum9_fwd: bad arguments");
+    hipLaunchKernelGGL(shift_sum9_fwd_kernel, dim3(gd_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, u, bias, y, H, W);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_shift_sum9_bwd(const float* dy, float* du, int B, int H, int W, void* stream) {
+    GD_CHECK_ARG(dy && du && B > 0 && B <= 65535 && H > 0 && H <= 65535 && W > 0, "gd_shift_sum9_bwd: bad arguments");
+    hipLaunchKernelGGL(shift_sum9_bwd_kernel, dim3(gd_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, dy, du, H, W);
     GD_LAUNCH_CHECK();
     return 0;
 }

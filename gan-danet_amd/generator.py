@@ -167,9 +167,25 @@ class FlexibleUpsamplingModule(nn.Module):
                 x = self.transition_layers[i](x)
         up = self.upsample
         x = up[3](up[1](up[0](x), ACT_RELU))
-        x = up[7](up[5](up[4](x), ACT_RELU))
-        x = ops.SkipFuseFn.apply(x, *[adj.weight for adj in self.channel_adjust], *skips[::-1])
-        return self.final(x)
+        c = up[5](up[4](x), ACT_RELU)                      # (B, 64, 2H, 2W)
+        fw = self.final.weight
+        if fw.shape[0] != 1 or tuple(fw.shape[2:]) != (3, 3):
+            x = ops.SkipFuseFn.apply(up[7](c), *[adj.weight for adj in self.channel_adjust], *skips[::-1])
+            return self.final(x)
+        # Tail as written (generator.py:242-247): final(up2(c) + sum_k adjust_k(resize4(f_k))).  Every map after the
+        # last ReLU is linear and the resizes act per channel, so the channel contraction of `final` is pulled in
+        # front of them: nine "tap planes" t_tap = sum_ch w[ch][tap] c_ch (a 1x1 conv 64 -> 9 at 2H x 2W) and
+        # sum_ch (w[.][tap] A_k)[ch] f_k,ch (1x1 convs C_k -> 9 at H x W, final and channel_adjust weights composed)
+        # are resized and summed with their tap shifts.  The 4H x 4W stage carries 9 planes instead of 64 channels
+        # (7x less HBM traffic there, no 64-channel 4H x 4W tensor kept for backward).  Same parameters, same
+        # result up to fp32 re-association.
+        w9 = fw.reshape(fw.shape[1], 9).t()                # (9, 64): w9[tap][ch]
+        t = ops.conv2d(c, w9.reshape(9, -1, 1, 1).contiguous())
+        u = up[7](t)                                       # (B, 9, 4H, 4W)
+        wk = [(w9 @ adj.weight.reshape(adj.weight.shape[0], -1)).reshape(9, -1, 1, 1).contiguous()
+              for adj in self.channel_adjust]
+        u = ops.SkipFuseFn.apply(u, *wk, *skips[::-1])
+        return ops.ShiftSum9Fn.apply(u, self.final.bias)
 
 
 # ---- exported by the reference but not used by the train loop: compositions of the same kernels --------

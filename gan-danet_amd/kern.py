@@ -303,6 +303,24 @@ def bicubic_fwd(x: Tensor, Ho: int, Wo: int, rsh: float, rsw: float) -> Tensor:
     return y
 
 
+def shift_sum9_fwd(u: Tensor, bias: Optional[Tensor]) -> Tensor:
+    _dense(u, "tap planes")
+    B, nine, H, W = u.shape
+    if nine != 9:
+        raise L.GandanetError(f"shift_sum9: expected (B, 9, H, W) tap planes, got {tuple(u.shape)}")
+    y = torch.empty(B, 1, H, W, device=u.device, dtype=torch.float32)
+    L.check(lib().gd_shift_sum9_fwd(_ptr(u), _ptr(bias), _ptr(y), B, H, W, _stream()), "gd_shift_sum9_fwd")
+    return y
+
+
+def shift_sum9_bwd(dy: Tensor) -> Tensor:
+    _dense(dy, "dy")
+    B, _, H, W = dy.shape
+    du = torch.empty(B, 9, H, W, device=dy.device, dtype=torch.float32)
+    L.check(lib().gd_shift_sum9_bwd(_ptr(dy), _ptr(du), B, H, W, _stream()), "gd_shift_sum9_bwd")
+    return du
+
+
 def combine_inputs(lr: Tensor, aux: Tensor, s1: float = 0.5, s2: float = 0.25) -> Tensor:
     """cat([bicubic(lr, scale_factor=s1), bicubic(aux, scale_factor=s2)], 1) in one launch
     (GAN_DANet_train.ipynb:L218-224; output size floor(in * scale) like F.interpolate)"""

@@ -508,6 +508,21 @@ class SkipFuseFn(Function):
         return (dout, *gw, *gf)
 
 
+class ShiftSum9Fn(Function):
+    """y = bias + sum_tap shift(u_tap): the 3x3 / pad 1 / one-output-channel conv applied to its nine pre-contracted tap
+    planes (see FlexibleUpsamplingModule.forward)"""
+
+    @staticmethod
+    def forward(ctx, u, bias):
+        ctx.has_bias = bias is not None
+        return K.shift_sum9_fwd(_c(u), bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return K.shift_sum9_bwd(dy), (K.dot(dy, None).view(1) if ctx.has_bias else None)
+
+
 class MaxPool2Fn(Function):
     @staticmethod
     def forward(ctx, x):

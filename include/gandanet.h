@@ -158,6 +158,12 @@ int gd_bicubic_fwd(const float* x, int BC, int Hi, int Wi, float* y, int Ho, int
                    float rscale_w, void* stream);
 int gd_bicubic_bwd(const float* dy, int BC, int Hi, int Wi, float* dx, int Ho, int Wo, float rscale_h,
                    float rscale_w, void* stream);
+/* last step of the generator tail (generator.py:242-247) in its collapsed form: final = conv3x3(C -> 1, pad 1) of
+ * up2(c) + resize4(s) equals bias + sum over the nine taps of SHIFTED "tap planes" u (B, 9, H, W), each the channel
+ * contraction sum_ch w[ch][tap] (.) done at low resolution and then resized (linear maps commute): only 9 planes instead
+ * of C channels live at the output resolution.  y (B, 1, H, W); the backward scatters dy into the nine shifted planes. */
+int gd_shift_sum9_fwd(const float* u, const float* bias, float* y, int B, int H, int W, void* stream);
+int gd_shift_sum9_bwd(const float* dy, float* du, int B, int H, int W, void* stream);
 /* input preamble of the train step (GAN_DANet_train.ipynb:L218-224), one launch, no cat pass:
  *   out (B, C1+C2, Ho, Wo) = cat([F.interpolate(lr (B,C1,H1,W1), scale_factor=1/rs1, mode='bicubic'),
  *                                 F.interpolate(aux (B,C2,H2,W2), scale_factor=1/rs2, mode='bicubic')], dim=1)

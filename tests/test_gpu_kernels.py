@@ -432,3 +432,25 @@ def test_nhwc_stem_pool_l1(gd, ci):
     gl = K.nhwc_l1_grad(a, b2, up, True)
     ref = 0.5 / fa.numel() * torch.sign(fa - fb) * (fa > 0).float()
     assert_close(_nchw(gl), ref, 1e-2, "l1 grad")
+
+
+def test_shift_sum9_is_the_one_hot_3x3_conv(gd):
+    """ShiftSum9Fn (last step of the collapsed generator tail): bias + sum_tap shift(u_tap) equals conv3x3(u, E), E the
+    one-hot (1, 9, 3, 3) kernel with E[0][tap][tap // 3][tap % 3] = 1; forward and both gradients, exact up to the order
+    of nine fp32 additions"""
+    ops, _ = _ops()
+    u = seeded((2, 9, 13, 37), 161)
+    bias = seeded((1,), 162)
+    E = torch.zeros(1, 9, 3, 3)
+    for t in range(9):
+        E[0, t, t // 3, t % 3] = 1.0
+    ur, br = u.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = F.conv2d(ur, E, br, padding=1)
+    go = seeded(tuple(yr.shape), 163)
+    yr.backward(go)
+    ug, bg = u.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    y = ops.ShiftSum9Fn.apply(ug, bg)
+    y.backward(go.to(DEV))
+    assert_close(y, yr, 1e-6, "y")
+    assert_close(ug.grad, ur.grad, 1e-7, "du")
+    assert_close(bg.grad, br.grad, 1e-5, "dbias")
