@@ -502,3 +502,45 @@ def test_generator_eval_forward_inference_tiles_vs_oracle(gd, shape):
     assert tuple(y32.shape) == (shape[0], 1, 4 * shape[2], 4 * shape[3])
     assert_close(y32, yo, 1e-3, "eval forward fp32")
     assert_close(y16, yo, 5e-2, "eval forward bf16", rell2)
+
+
+def test_pam_flash_backward_two_forms_agree_at_bench_and_max_size(gd):
+    """size-independent check where the oracle cannot go: the fused backward (dQ from the key-parallel kernel, bf16 parts
+    per key block) against the two-kernel form (dQ recomputed by a query-parallel kernel) on the same packed operands,
+    at the bench sequence length (N = 256 * 256, C = 184) and at BASELINE config 5's (N = 512 * 512, C = 64); dK / dV come
+    from the same arithmetic and must be bit-identical, dQ differs by the bf16 rounding of the parts"""
+    from gan_danet_amd import kern as K
+    for (C, side) in ((184, 256), (64, 512)):
+        B, N, r = 1, side * side, max(1, C // 8)
+        Np, Cp = (N + 255) // 256 * 256, (C + 31) // 32 * 32
+        g = torch.Generator(device=DEV).manual_seed(7)
+        q = torch.randn(B, r, N, device=DEV, generator=g) * 0.5
+        k = torch.randn(B, r, N, device=DEV, generator=g) * 0.5
+        v = torch.randn(B, C, N, device=DEV, generator=g)
+        x = torch.randn(B, C, N, device=DEV, generator=g)
+        do = torch.randn(B, C, N, device=DEV, generator=g)
+        gamma = torch.full((1,), 0.5, device=DEV)
+        ones = Cp - 1 if C < Cp else -1
+        _, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32))
+        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31)
+        vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones)
+        out, o, lse = torch.empty_like(x), torch.empty_like(x), torch.empty(B, N, device=DEV)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0)
+        # rows of P sum to one: attention output of a constant V is that constant (checked through lse-consistency of
+        # the backward below); here: finite output
+        assert torch.isfinite(out).all()
+        _, dot_ = K.pack_bf16(do, C, N, scale=gamma, t_shape=(Np, Cp))
+        _, delta = K.chan_dot(do, o, gamma)
+        res = {}
+        for fused in (True, False):
+            K.PAM_DQ_FUSED = fused
+            try:
+                dq = torch.empty(B, 32, Np, device=DEV)
+                dk = torch.empty(B, 32, Np, device=DEV)
+                dv = torch.empty(B, Cp, Np, device=DEV)
+                K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dq, dk, dv, r_alg=r, c_alg=C)
+            finally:
+                K.PAM_DQ_FUSED = True
+            res[fused] = (dq[:, :r].clone(), dk[:, :r].clone(), dv[:, :C].clone())
+        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+        assert_close(res[True][0], res[False][0].cpu(), 1e-2, f"dQ fused vs recomputed, N={N}", rell2)
