@@ -205,6 +205,20 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
             if (ps >= HsWs) continue;
             const int qa = ps / Ws;
             const int pn = (d.sub_oy + qa * sstep) * d.Wo + d.sub_ox + (ps - qa * Ws) * sstep;
+            // residual / accumulate operands: all loads before the first store (see conv3x3_halo_kernel's epilogue)
+            float rsv[16], oldv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                rsv[e] = (d.res && m < d.M) ? d.res[(long)b * d.res_bs + (long)m * HoWo + pn] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                const long idx = d.out_layout == 0 ? (long)b * d.y_bs + (long)m * HoWo + pn
+                                                   : (long)b * d.y_bs + (long)pn * d.ldo + m;
+                oldv[e] = (d.accumulate && !d.out_bf16 && m < d.Mstore) ? reinterpret_cast<const float*>(d.y)[idx] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
@@ -212,19 +226,14 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
                 float v = acc[i][j][e] * alpha;
                 if (m < d.M) {
                     if (d.bias) v += d.bias[m];
-                    if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HoWo + pn];
+                    v += rsv[e];
                 }
                 if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
                 const long idx = d.out_layout == 0 ? (long)b * d.y_bs + (long)m * HoWo + pn
                                                    : (long)b * d.y_bs + (long)pn * d.ldo + m;
-                if (d.out_bf16) {
-                    reinterpret_cast<unsigned short*>(d.y)[idx] = gd_f2bf(v);
-                } else {
-                    float* yp = reinterpret_cast<float*>(d.y) + idx;
-                    if (d.accumulate) v += *yp;
-                    *yp = v;
-                }
+                if (d.out_bf16) reinterpret_cast<unsigned short*>(d.y)[idx] = gd_f2bf(v);
+                else reinterpret_cast<float*>(d.y)[idx] = v + oldv[e];
             }
         }
     }
@@ -387,18 +396,27 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
         for (int j = 0; j < TN; ++j) {
             const int pn = n0 + wn * TN * 32 + j * 32 + r;
             if (pn >= HW) continue;
+            // residual / accumulate operands: all loads before the first store (see conv3x3_halo_kernel's epilogue)
+            float rsv[16], oldv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                rsv[e] = (d.res && m < d.M) ? d.res[(long)b * d.res_bs + (long)m * HW + pn] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                oldv[e] = (d.accumulate && m < d.M) ? reinterpret_cast<const float*>(d.y)[(long)b * d.y_bs + (long)m * HW + pn] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
                 if (m >= d.M) continue;
-                float v = acc[i][j][e] * alpha;
+                float v = acc[i][j][e] * alpha + rsv[e];
                 if (d.bias) v += d.bias[m];
-                if (d.res) v += d.res[(long)b * d.res_bs + (long)m * HW + pn];
                 if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
-                float* yp = reinterpret_cast<float*>(d.y) + (long)b * d.y_bs + (long)m * HW + pn;
-                if (d.accumulate) v += *yp;
-                *yp = v;
+                reinterpret_cast<float*>(d.y)[(long)b * d.y_bs + (long)m * HW + pn] = v + oldv[e];
             }
         }
 }
