@@ -1,0 +1,116 @@
+"""Checkpoint / ensemble layer around the train step.
+
+* ``save_generator`` / ``load_generator``: the reference's ``best_model.pth`` (GAN_DANet_train.ipynb:L275, L282, L299):
+  the generator's ``state_dict`` with the reference's own keys -- a file written here loads into the reference
+  module and vice versa.
+* ``EarlyStopping``: the patience / min_delta rule of L271-283.
+* ``save_training_state`` / ``load_training_state``: what the reference does NOT keep -- discriminator, both AdamW
+  states, the LR schedulers and the epoch counter -- so that a run resumes bit-for-bit.
+* ensemble (deep_ensemble.ipynb c0:270-337): members are independent replicas with seeds 42 + i; on an N-GPU node
+  member i trains on rank i % N with NO gradient exchange (``GanTrainer(reduce_gradients=False)``), and the
+  prediction mean / spread of ``compute_uncertainty`` (c0:410-448) is a reduction over the member axis.
+
+Files are read with ``torch.load(weights_only=True)`` only.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def save_generator(G: nn.Module, path: str = "best_model.pth") -> None:
+    torch.save(G.state_dict(), path)
+
+
+def load_generator(G: nn.Module, path: str = "best_model.pth", device=None) -> nn.Module:
+    G.load_state_dict(torch.load(path, map_location=device or "cpu", weights_only=True))
+    return G
+
+
+class EarlyStopping:
+    """L259-283: keep the best generator, stop after ``patience`` epochs without an improvement > ``min_delta``."""
+
+    def __init__(self, patience: int = 10, min_delta: float = 0.0, path: str = "best_model.pth") -> None:
+        self.patience, self.min_delta, self.path = patience, min_delta, path
+        self.best_loss = float("inf")
+        self.trigger_times = 0
+
+    def step(self, avg_epoch_loss_g: float, G: nn.Module) -> bool:
+        """returns True when training should stop (the best weights are then already loaded back into G)"""
+        if avg_epoch_loss_g < self.best_loss - self.min_delta:
+            self.best_loss = avg_epoch_loss_g
+            self.trigger_times = 0
+            save_generator(G, self.path)
+            return False
+        self.trigger_times += 1
+        if self.trigger_times >= self.patience:
+            load_generator(G, self.path, next(G.parameters()).device)
+            return True
+        return False
+
+
+def save_training_state(path: str, trainer, epoch: int, schedulers: Sequence = (), extra: Optional[Dict] = None) -> None:
+    state = {
+        "epoch": int(epoch),
+        "G": trainer.G.state_dict(),
+        "D": trainer.D.state_dict(),
+        "opt_g": trainer.opt_g.state_dict(),
+        "opt_d": trainer.opt_d.state_dict(),
+        "schedulers": [s.state_dict() for s in schedulers],
+        "extra": dict(extra or {}),
+    }
+    if getattr(trainer, "input_attention", None) is not None:
+        state["input_attention"] = trainer.input_attention.state_dict()
+    tmp = path + ".tmp"
+    torch.save(state, tmp)
+    os.replace(tmp, path)          # a crash mid-write never leaves a truncated checkpoint under the final name
+
+
+def load_training_state(path: str, trainer, schedulers: Sequence = ()) -> Dict:
+    dev = next(trainer.G.parameters()).device
+    state = torch.load(path, map_location=dev, weights_only=True)
+    trainer.G.load_state_dict(state["G"])
+    trainer.D.load_state_dict(state["D"])
+    trainer.opt_g.load_state_dict(state["opt_g"])
+    trainer.opt_d.load_state_dict(state["opt_d"])
+    if "input_attention" in state and getattr(trainer, "input_attention", None) is not None:
+        trainer.input_attention.load_state_dict(state["input_attention"])
+    for s, sd in zip(schedulers, state["schedulers"]):
+        s.load_state_dict(sd)
+    return {"epoch": state["epoch"], "extra": state["extra"]}
+
+
+# ---- ensemble ------------------------------------------------------------------------------------------------
+def member_seed(i: int) -> int:
+    return 42 + i                                                    # deep_ensemble.ipynb c0:284
+
+
+def set_seed(seed: int) -> None:                                     # deep_ensemble.ipynb c0:286-292
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def members_of_rank(num_ensemble: int, rank: int, world: int) -> List[int]:
+    """independent members spread over the ranks of a node: member i -> rank i % world"""
+    return [i for i in range(num_ensemble) if i % world == rank]
+
+
+def member_path(ensemble_dir: str, i: int) -> str:
+    return os.path.join(ensemble_dir, f"best_model_member_{i + 1}.pth")   # c0:310 (1-based file names)
+
+
+@torch.no_grad()
+def predict_ensemble(models: Iterable[nn.Module], x: torch.Tensor):
+    """mean and standard deviation over the members' predictions (c0:339-448: ``np.mean`` / ``np.std`` over the member
+    axis, population std).  The member forwards are the HIP generator; the reduction over a handful of members is
+    plain tensor arithmetic."""
+    preds = torch.stack([m(x) for m in models], 0)
+    return preds.mean(0), preds.std(0, unbiased=False)

@@ -33,21 +33,29 @@ class StepOutput:
     hr: torch.Tensor
 
 
+class _NoReduce:
+    def reduce(self) -> None:
+        return None
+
+
 class GanTrainer:
     def __init__(self, G: nn.Module, D: nn.Module, perceptual: Optional[nn.Module] = None, lr_g: float = 2e-4,
                  lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
                  compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
-                 batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None) -> None:
+                 batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None,
+                 reduce_gradients: bool = True) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
         # optional gate on the combined input (the notebook's attention_module / senet_module, L145-171,
         # L229-232: SqueezeExcitation or CBAMBlock); its parameters join the generator's optimiser (L165-175)
         self.input_attention = input_attention
         g_params = list(G.parameters()) + (list(input_attention.parameters()) if input_attention is not None else [])
-        ws = world_size()
+        # reduce_gradients=False: this process trains an INDEPENDENT replica (an ensemble member, checkpoint.py) even
+        # when torch.distributed is initialised -- no gradient exchange, no 1/world scaling
+        ws = world_size() if reduce_gradients else 1
         self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
         self.opt_g = AdamW(g_params, lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
-        self.red_d = GradReducer(D.parameters())
-        self.red_g = GradReducer(g_params)
+        self.red_d = GradReducer(D.parameters()) if reduce_gradients else _NoReduce()
+        self.red_g = GradReducer(g_params) if reduce_gradients else _NoReduce()
         # TVLoss divides by the batch size twice (losses.py:82-87): per-shard TV averaged over ranks is `world`
         # times the single-device global-batch value.  Default = plain DDP semantics (per-shard loss, as the
         # per-shard oracle computes it); set tv_global_batch_semantics to scale it back by 1/world.
