@@ -489,6 +489,7 @@ constexpr int WNPIX = WPH * PW;        // 204 patch pixels
 constexpr int DYLD = WTH * TW + 8;     // dY rows: 128 pixels + 8 pad (272 B): conflict-free 16-byte reads
 
 struct WgradArgs {
+    const unsigned short* dy16;      // optional bf16 copy of dy, dense (B, M, Ho, Wo): read instead of dy
     const float* dy; long dy_bs;
     const float* x; long x_bs;
     const float* in_scale; const float* in_shift; int in_relu;
@@ -547,6 +548,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             if (CS && idx >= 32 * 32) break;
             const int m = idx >> 5, v = idx & 31;
             const int yy = y0 + (v >> 3), xx = x0 + (v & 7) * 4;
+            if (a.dy16) {       // pre-converted dY: 8-byte copies, no convert (the tile is re-read once per ci chunk)
+                uint2 w = make_uint2(0u, 0u);
+                if (m0 + m < a.M && yy < a.Ho) {
+                    const unsigned short* p = a.dy16 + ((long)b * a.M + m0 + m) * HWo + (long)yy * a.Wo + xx;
+                    if (vec_ok && xx + 3 < a.Wo) {
+                        w = *reinterpret_cast<const uint2*>(p);
+                    } else {
+                        unsigned int e0 = xx + 0 < a.Wo ? p[0] : 0u, e1 = xx + 1 < a.Wo ? p[1] : 0u;
+                        unsigned int e2 = xx + 2 < a.Wo ? p[2] : 0u, e3 = xx + 3 < a.Wo ? p[3] : 0u;
+                        w.x = e0 | (e1 << 16);
+                        w.y = e2 | (e3 << 16);
+                    }
+                }
+                *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
+                continue;
+            }
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + m < a.M && yy < a.Ho) {
                 const float* p = dyb + (long)(m0 + m) * HWo + (long)yy * a.Wo + xx;
@@ -636,15 +653,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 }  // namespace
 
 // dw (Cout, Cin, 3, 3) fp32 is overwritten.  Same input-transform contract as gd_conv2d.
-extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, const float* in_scale,
-                                const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, int stride,
-                                float* dw, void* stream) {
+extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
+                                const float* in_scale, const float* in_shift, int in_relu, int B, int Cout, int Cin, int H,
+                                int W, int stride, float* dw, void* stream) {
     GD_CHECK_ARG(dy && x && dw, "gd_conv3x3_wgrad: null pointer");
     GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gd_conv3x3_wgrad: bad sizes");
     GD_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gd_conv3x3_wgrad: in_scale/in_shift must come together");
     hipStream_t s = (hipStream_t)stream;
     GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) == hipSuccess, "gd_conv3x3_wgrad: memset failed");
     WgradArgs a;
+    a.dy16 = (const unsigned short*)dy_bf16;
     a.dy = dy; a.dy_bs = dy_bs; a.x = x; a.x_bs = x_bs;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.dw = dw; a.B = B; a.M = Cout; a.Ck = Cin; a.H = H; a.W = W;

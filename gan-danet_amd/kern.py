@@ -205,8 +205,12 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
     _, Cin, Hi, Wi = x.shape
     dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
     if USE_CONV3X3_FAST and k == 3 and stride in (1, 2) and pad == 1 and precision == L.PREC_BF16:
-        L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift), int(in_relu), B,
-                                       Cout, Cin, Hi, Wi, stride, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+        dy16 = None
+        if Cout > 32 and Cin >= 4 * 32:
+            # every 32-channel chunk of ci re-reads each dY tile: hand the kernel a bf16 copy made once
+            dy16, _ = pack_bf16(dy.view(B, Cout, Ho * Wo), Cout, Ho * Wo, plain_shape=(Cout, Ho * Wo))
+        L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(dy16), _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift),
+                                       int(in_relu), B, Cout, Cin, Hi, Wi, stride, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
         return dw
     if k == 1 and stride == 1 and pad == 0 and in_scale is None:
         # 1x1: dW = dY X^T with both operands pixel-contiguous -> plain NT GEMM (float4-staged when aligned)

@@ -86,8 +86,10 @@ size_t gd_conv3x3_ws_bytes(int M, int Ck);
 int gd_conv3x3_eligible(const gd_conv_desc* d);
 int gd_conv3x3(const gd_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
 /* weight gradient of the same convolution (bf16 MFMA, fp32 atomics across the pixel splits):
- * dw (Cout, Cin, 3, 3) = sum_{b,p} dy[b][co][p] * relu?(x*in_scale + in_shift)[b][ci][p (+) tap]; dw is overwritten. */
-int gd_conv3x3_wgrad(const float* dy, long dy_bs, const float* x, long x_bs, const float* in_scale,
+ * dw (Cout, Cin, 3, 3) = sum_{b,p} dy[b][co][p] * relu?(x*in_scale + in_shift)[b][ci][p (+) tap]; dw is overwritten.
+ * dy_bf16 (may be NULL): a dense bf16 copy (B, Cout, Ho, Wo) of dy made by the caller (gd_pack_bf16); it is then read
+ * instead of dy -- worth it when Cin spans several 32-channel chunks, each of which re-reads every dY tile. */
+int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs, const float* in_scale,
                      const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, int stride, float* dw,
                      void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
 
