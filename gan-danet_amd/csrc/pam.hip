@@ -289,29 +289,29 @@ __device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld
 // 2.5 KB of wave-private LDS and 2 more MFMAs does not: each wave transposes its dS tile (LDS transpose read),
 // multiplies by its K rows, the four waves' partial dQ^T tiles are summed after the barrier and stored as bf16
 // [key block][query][32 d]; pam_dq_reduce_kernel sums the key blocks.  No atomics: deterministic.
-template <int CT, bool DQ>
-__global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
+template <int CT, bool DQ, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ lse,
     const float* __restrict__ delta, int N, int Npad, float* __restrict__ dkn, float* __restrict__ dv,
     unsigned short* __restrict__ dq_part) {
     constexpr int CP = CT * 32;
-    constexpr int NT = 256;
+    constexpr int NT = NW * 64, KEYS = NW * 32;    // NW = 4: 128 keys, two workgroups per CU; NW = 8: 256 keys, one
     constexpr int DLD = CP + 8;
     constexpr int NCHUNK = 128 + 128 * CT;
     constexpr int NPRE = (NCHUNK + NT - 1) / NT;
     constexpr bool RAGGED = (NCHUNK % NT) != 0;
-    __shared__ __attribute__((aligned(16))) unsigned short Vls[128 * DLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vls[KEYS * DLD];
     __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
     __shared__ float Ls[32], Ds[32];
     constexpr int XLD = 40;                                      // 80-byte rows: conflict-light 8-byte accesses
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[DQ ? 4 * 32 * XLD : 8];   // per wave: dS^T, then its dQ^T part
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[DQ ? NW * 32 * XLD : 8];   // per wave: dS^T, then its dQ^T part
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int j0 = blockIdx.x * 128 + wave * 32;
+    const int j0 = blockIdx.x * KEYS + wave * 32;
     const long nb = (long)b * Npad;
 
     bf16x8_t kfB[2];
@@ -326,10 +326,10 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
             knA[s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + s * 16 + 8 * h);
     }
     unsigned short* Xw = Xs + (DQ ? wave * 32 * XLD : 0);
-    unsigned short* part = DQ ? dq_part + ((long)b * (Npad / 128) + blockIdx.x) * Npad * 32 : nullptr;
+    unsigned short* part = DQ ? dq_part + ((long)b * (Npad / KEYS) + blockIdx.x) * Npad * 32 : nullptr;
     {
-        const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * 128) * CP;
-        for (int c = tid; c < 128 * (CP / 8); c += NT) {
+        const unsigned short* vsrc = vt + (nb + (long)blockIdx.x * KEYS) * CP;
+        for (int c = tid; c < KEYS * (CP / 8); c += NT) {
             const int row = c / (CP / 8), ch = c - row * (CP / 8);
             *reinterpret_cast<u32x4_t*>(Vls + row * DLD + ch * 8) =
                 *reinterpret_cast<const u32x4_t*>(vsrc + (long)row * CP + ch * 8);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
         for (int e = 0; e < 16; ++e) dvacc[ct][e] = 0.f;
 
     const bool key_ok = (j0 + r) < N;
-    const bool need_mask = (int)(blockIdx.x + 1) * 128 > N;
+    const bool need_mask = (int)(blockIdx.x + 1) * KEYS > N;
     const int nqt = (N + 31) / 32;
 
     // staging plan: 32-bit element offset inside the tile's Q or dO source and LDS slot.  Chunks 0..127 are Q, i.e.
@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
         }
         __syncthreads();
         if (DQ) {   // sum the four waves' parts: thread = (query, 4 d) ; 2 KiB contiguous per key block and query tile
-            const int q = tid >> 3, dg = (tid & 7) * 4;
+            const int q = (tid & 255) >> 3, dg = (tid & 7) * 4;
             float acc4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
+            for (int w4 = 0; w4 < NW; ++w4) {
                 const u32x2_t v2 = *reinterpret_cast<const u32x2_t*>(Xs + w4 * 32 * XLD + q * XLD + dg);
                 acc4[0] += gd_bf2f((unsigned short)(v2.x & 0xFFFFu));
                 acc4[1] += gd_bf2f((unsigned short)(v2.x >> 16));
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void pam_bwd_dkv3_kernel(
                 acc4[3] += gd_bf2f((unsigned short)(v2.y >> 16));
             }
             const u32x2_t o = {gd_pack_bf2(acc4[0], acc4[1]), gd_pack_bf2(acc4[2], acc4[3])};
-            *reinterpret_cast<u32x2_t*>(part + ((long)i0 + q) * 32 + dg) = o;
+            if (tid < 256) *reinterpret_cast<u32x2_t*>(part + ((long)i0 + q) * 32 + dg) = o;
         }
         if (qtile + 1 < nqt) store_tile();
         if (DQ || qtile + 1 < nqt) __syncthreads();
@@ -706,7 +706,15 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     return 0;
 }
 
-extern "C" size_t gd_pam_dq_part_bytes(int Npad) { return (size_t)(Npad / 128) * (size_t)Npad * 32 * sizeof(unsigned short); }
+// key block of the fused backward: 8 waves = 256 keys per workgroup (default; 18.0 ms at B=4, C=184) or 4 waves = 128
+// keys, two workgroups per CU (GD_PAM_DKV_NW=4; 18.9 ms and twice the dQ parts)
+static int pam_dkv_waves() {
+    static const int nw = getenv("GD_PAM_DKV_NW") ? atoi(getenv("GD_PAM_DKV_NW")) : 8;
+    return nw == 4 ? 4 : 8;
+}
+extern "C" size_t gd_pam_dq_part_bytes(int Npad) {
+    return (size_t)(Npad / (32 * pam_dkv_waves())) * (size_t)Npad * 32 * sizeof(unsigned short);
+}
 
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                 const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn,
@@ -722,14 +730,21 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, 
         // fused: the key-parallel kernel also emits bf16 dQ parts per key block, summed by a streaming kernel; the
         // batch is walked in slices that fit the caller's scratch buffer
         const int slice = (int)(dq_part_bytes / per_image < (size_t)B ? dq_part_bytes / per_image : (size_t)B);
+        const int nw_env = pam_dkv_waves();
         for (int b0 = 0; b0 < B; b0 += slice) {
             const int nb = B - b0 < slice ? B - b0 : slice;
             const long o32 = (long)b0 * Npad * 32, oc = (long)b0 * Npad * Cp, on = (long)b0 * N;
-            PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true>), dim3(Npad / 128, nb), dim3(256), 0, s,
-                                                         q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
-                                                         N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
+            if (nw_env == 8) {
+                PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true, 8>), dim3(Npad / 256, nb), dim3(512), 0, s,
+                                                             q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
+                                                             N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
+            } else {
+                PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true>), dim3(Npad / 128, nb), dim3(256), 0, s,
+                                                             q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
+                                                             N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
+            }
             hipLaunchKernelGGL(pam_dq_reduce_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const unsigned short*)dq_part,
-                               Npad / 128, Npad, dqn + o32);
+                               Npad / (nw_env == 8 ? 256 : 128), Npad, dqn + o32);
         }
         GD_LAUNCH_CHECK();
         return 0;
