@@ -6,19 +6,21 @@
 // The N x N matrices are never materialised.  d is zero-padded to 32, C to a multiple of 32 (Cp).
 //
 // Operand contract: q is packed PRE-SCALED by log2(e) (gd_pack_bf16 scale_imm), so every S tile comes out of the
-//   MFMA in the log2 domain, and the softmax shift (running max in the forward, log-sum-exp in the backward) and
-//   the backward's row term delta are fed in as the MFMA's accumulator input: exp2 is applied to the accumulator
-//   as it stands, no per-element multiply / subtract is left on the VALU.
+//   MFMA in the log2 domain.  The forward feeds its running row maximum through the spare k-slot d = 31 (k holds 1.0
+//   there), the backward feeds -log-sum-exp and the row term -delta in as the MFMA accumulator input: exp2 is applied
+//   to the accumulator as it stands, no per-element multiply / subtract is left on the VALU.
 // Forward: one workgroup = 8 waves = 256 queries (32 per wave), K/V streamed in 128-key tiles through LDS.
 //   S^T = K Q^T is computed with the KEY index on the accumulator rows and the QUERY on the lane, so
 //   * the row softmax is lane-local (+ one cross-half shuffle),
 //   * the probability tile is already the B operand of O^T = V P^T  (accumulator-as-operand, no LDS trip),
 //   * O^T comes out with the query on the lane: the online rescale is lane-local and the store to the NCHW
 //     output is coalesced along pixels.
-// Backward: one workgroup = 4 waves = 128 keys (32 per wave) holding dV^T and dK^T in accumulators while it
-//   sweeps the queries in 32-row tiles; S and dP are computed with the key on the lane, so P and dS are
-//   directly the B operands of dV^T += dO^T P and dK^T += Q^T dS; only dS crosses LDS (for dQ += dS K, which is
-//   accumulated across workgroups with fp32 atomics in 128-byte row segments).
+// Backward: one workgroup = 8 (or 4) waves = 256 (128) keys, 32 per wave, holding dV^T and dK^T in accumulators while
+//   it sweeps the queries in 32-row tiles; S and dP are computed with the key on the lane, so P and dS are directly
+//   the B operands of dV^T += dO^T P and dK^T += Q^T dS.  For dQ the dS tile is turned around through wave-private
+//   LDS (transpose read), multiplied by the wave's K rows and the workgroup's sum is stored as a bf16 part per key
+//   block; pam_dq_reduce_kernel adds the key blocks.  No atomics anywhere.  (pam_bwd_dq_kernel: the scratch-free
+//   alternative, a query-parallel kernel that recomputes S and dP.)
 #include <stdlib.h>
 
 #include "common.h"
@@ -265,8 +267,8 @@ constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
 // backward, part 1c: dK^T / dV^T, transpose-read variant.  Only Q [i][d] and dO [i][c] are staged per query
 // tile; the "transposed" A operands of dV^T += dO^T P and dK^T += Q^T dS are taken from the SAME images with
 // ds_read_b64_tr_b16 (4 query rows x 16 channel columns per 16-lane group), so the q^T / dO^T copies, half of
-// the staging traffic and half of the tile LDS disappear.  V rows of the workgroup's 128 keys live in LDS.
-// 4 waves per workgroup and two independent workgroups per CU: their phases drift apart, so one's MFMA
+// the staging traffic and half of the tile LDS disappear.  V rows of the workgroup's keys live in LDS.
+// NW = 4 (without dQ): 4 waves per workgroup and two independent workgroups per CU: their phases drift apart, so one's MFMA
 // segments overlap the other's softmax / staging segments instead of all eight waves meeting at one barrier.
 // =====================================================================================================
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -287,7 +289,7 @@ __device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld
 // DQ: also emit this key block's contribution to dQ.  dS is already in registers here; recomputing S and dP in a
 // second query-parallel kernel (pam_bwd_dq_kernel) costs 14 MFMAs per 32x32 tile, turning the tile around through
 // 2.5 KB of wave-private LDS and 2 more MFMAs does not: each wave transposes its dS tile (LDS transpose read),
-// multiplies by its K rows, the four waves' partial dQ^T tiles are summed after the barrier and stored as bf16
+// multiplies by its K rows, the NW waves' partial dQ^T tiles are summed after the barrier and stored as bf16
 // [key block][query][32 d]; pam_dq_reduce_kernel sums the key blocks.  No atomics: deterministic.
 template <int CT, bool DQ, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
             }
         }
         __syncthreads();
-        if (DQ) {   // sum the four waves' parts: thread = (query, 4 d) ; 2 KiB contiguous per key block and query tile
+        if (DQ) {   // sum the NW waves' parts: thread = (query, 4 d) ; 2 KiB contiguous per key block and query tile
             const int q = (tid & 255) >> 3, dg = (tid & 7) * 4;
             float acc4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
