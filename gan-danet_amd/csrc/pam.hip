@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
     __shared__ float Ls[32], Ds[32];
-    constexpr int XLD = 40;                                      // 80-byte rows: conflict-light 8-byte accesses
+    constexpr int XLD = 36;                                      // 72-byte rows: 32 lanes x 8 bytes hit 32 distinct bank pairs (80-byte rows: 2-way, PMC)
     __shared__ __attribute__((aligned(16))) unsigned short Xs[DQ ? NW * 32 * XLD : 8];   // per wave: dS^T, then its dQ^T part
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
