@@ -286,6 +286,22 @@ __device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld
     return f;
 }
 
+// dO tile image: rows of DOLD = CP + 32 elements (448 B at CP = 192: 28 sixteen-byte units, 28 = 12 mod 16) with the
+// 16-byte chunk index XOR-swizzled by (row >> 2) & 3.  Both ways the tile is read are then bank-conflict free:
+//   plain 16-byte reads, 16 rows x one chunk per pass : units {0,12,8,4} (row & 3) + {c^0..c^3} (row >> 2) -> 16 distinct;
+//   transpose reads, 4 rows x 4 chunks per 32-lane pass: units {0,12,8,4} + {g..g+3}              -> 16 distinct
+// (with plain 400-byte rows the transpose reads ran 2-way conflicted on half the banks: PMC SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int do_off(int row, int chunk, int ld) { return row * ld + ((chunk ^ ((row >> 2) & 3)) << 3); }
+__device__ __forceinline__ bf16x8_t read_tr_frag_sw(const unsigned short* X, int ld, int s, int ct, int lane) {
+    const int li = lane & 15, hh = lane >> 5;
+    const int row = 16 * s + 4 * hh + (li >> 2);
+    const int chunk = 4 * ct + 2 * ((lane >> 4) & 1) + ((li & 3) >> 1), sub = 4 * (li & 1);
+    const s16x4_t lo = lds_tr16(X + do_off(row, chunk, ld) + sub);          // queries 16s + 4h + 0..3
+    const s16x4_t hi = lds_tr16(X + do_off(row + 8, chunk, ld) + sub);      // queries 16s + 8 + 4h + 0..3
+    const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return f;
+}
+
 // DQ: also emit this key block's contribution to dQ.  dS is already in registers here; recomputing S and dP in a
 // second query-parallel kernel (pam_bwd_dq_kernel) costs 14 MFMAs per 32x32 tile, turning the tile around through
 // 2.5 KB of wave-private LDS and 2 more MFMAs does not: each wave transposes its dS tile (LDS transpose read),
@@ -305,7 +321,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
     constexpr bool RAGGED = (NCHUNK % NT) != 0;
     __shared__ __attribute__((aligned(16))) unsigned short Vls[KEYS * DLD];
     __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * B_QLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DLD];
+    constexpr int DOLD = CP + 32;                                // dO rows, chunk-swizzled (do_off)
+    __shared__ __attribute__((aligned(16))) unsigned short dOs[32 * DOLD];
     __shared__ float Ls[32], Ds[32];
     constexpr int XLD = 36;                                      // 72-byte rows: 32 lanes x 8 bytes hit 32 distinct bank pairs (80-byte rows: 2-way, PMC)
     __shared__ __attribute__((aligned(16))) unsigned short Xs[DQ ? NW * 32 * XLD : 8];   // per wave: dS^T, then its dQ^T part
@@ -367,9 +384,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
             const int c2 = c - 128;
             const int i = c2 / (4 * CT), ch = c2 - i * (4 * CT);
             so = (unsigned int)(i * CP + ch * 8);
-            dof = (unsigned int)(i * DLD + ch * 8);
+            dof = (unsigned int)do_off(i, ch, DOLD);
         }
-        plan[k] = so | (dof << 16);          // both < 32 * 200
+        plan[k] = so | (dof << 16);          // both < 2^16
     }
     const bool last_ok = !RAGGED || (tid + (NPRE - 1) * NT) < NCHUNK;
     const bool q_round0 = __builtin_amdgcn_readfirstlane(tid < 128 ? 1 : 0) != 0;
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
         }
 #pragma unroll
         for (int s = 0; s < 2 * CT; ++s) {
-            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + r * DLD + s * 16 + 8 * h);
+            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(dOs + do_off(r, 2 * s + h, DOLD));
             const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vls + (wave * 32 + r) * DLD + s * 16 + 8 * h);
             dpacc = mfma_bf16(da, vb, dpacc);
         }
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pam_bwd_dkv3_kernel(
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_tr_frag(dOs, DLD, s, ct * 32, lane), pf[s], dvacc[ct]);
+            for (int s = 0; s < 2; ++s) dvacc[ct] = mfma_bf16(read_tr_frag_sw(dOs, DOLD, s, ct, lane), pf[s], dvacc[ct]);
         f32x16_t dqp;
         if (DQ) {
             // transpose read = the B operand (lane = query, k = key) of dQ^T[d][i] += K^T[d][j] dS^T[j][i]
