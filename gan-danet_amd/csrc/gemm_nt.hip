@@ -129,6 +129,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
         }
 #pragma unroll
         for (int i = 0; i < RBV; ++i) {
+            if (d.in_scale) {       // plain (non-im2col) operand: B row n is input channel n -> fused BN affine (+ ReLU)
+                const int n = n0 + r0v + 32 * i;
+                if (n < d.N) {
+                    const float sc = d.in_scale[n], sh = d.in_shift[n];
+                    vb[i].x = fmaf(vb[i].x, sc, sh); vb[i].y = fmaf(vb[i].y, sc, sh);
+                    vb[i].z = fmaf(vb[i].z, sc, sh); vb[i].w = fmaf(vb[i].w, sc, sh);
+                    if (d.in_relu) {
+                        vb[i].x = fmaxf(vb[i].x, 0.f); vb[i].y = fmaxf(vb[i].y, 0.f);
+                        vb[i].z = fmaxf(vb[i].z, 0.f); vb[i].w = fmaxf(vb[i].w, 0.f);
+                    }
+                }
+            }
             if constexpr (BF16) {
                 uint2 w;
                 w.x = gd_pack_bf2(vb[i].x, vb[i].y);
@@ -157,7 +169,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int n = n0 + r0 + 8 * i;
-                rb[i] = (k_ok && n < d.N) ? bp[(long)n * d.ldb] : 0.f;
+                float v = (k_ok && n < d.N) ? bp[(long)n * d.ldb] : 0.f;
+                if (d.in_scale && k_ok && n < d.N) {
+                    v = fmaf(v, d.in_scale[n], d.in_shift[n]);
+                    if (d.in_relu) v = fmaxf(v, 0.f);
+                }
+                rb[i] = v;
             }
         } else {
             const int oy = (int)(kr / d.Wo), ox = (int)(kr - (long)oy * d.Wo);
@@ -256,7 +273,7 @@ int launch(const gd_gemm_nt_desc& d, int ktiles, int splits, hipStream_t s) {
     dim3 grid(gd_cdiv(d.N, BN), gd_cdiv(d.M, BM), d.B * splits);
     // float4 staging needs: plain operands, every row start / segment / batch offset a multiple of 4 floats from a
     // 16-byte aligned base, and k tiles that never straddle a segment
-    const bool vec = !d.im2col && !d.in_scale && d.klen % BK == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+    const bool vec = !d.im2col && d.klen % BK == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
                      d.a_ss % 4 == 0 && d.b_ss % 4 == 0 && d.a_bs % 4 == 0 && d.b_bs % 4 == 0 &&
                      ((uintptr_t)d.a % 16) == 0 && ((uintptr_t)d.bm % 16) == 0;
     if (d.precision == GD_PREC_BF16) {

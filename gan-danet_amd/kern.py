@@ -212,10 +212,12 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
         L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(dy16), _ptr(x), xbs, _ptr(in_scale), _ptr(in_shift),
                                        int(in_relu), B, Cout, Cin, Hi, Wi, stride, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
         return dw
-    if k == 1 and stride == 1 and pad == 0 and in_scale is None:
-        # 1x1: dW = dY X^T with both operands pixel-contiguous -> plain NT GEMM (float4-staged when aligned)
+    if k == 1 and stride == 1 and pad == 0:
+        # 1x1: dW = dY X~^T with both operands pixel-contiguous -> plain NT GEMM (float4-staged when aligned); a fused
+        # BN affine (+ReLU) of the input is a per-row transform of the B operand
         gemm_nt(B=1, M=Cout, N=Cin, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0, b_ss=xbs,
-                ldb=Hi * Wi, c=dw, c_bs=0, ldc=Cin, precision=precision)
+                ldb=Hi * Wi, c=dw, c_bs=0, ldc=Cin, precision=precision, in_scale=in_scale, in_shift=in_shift,
+                in_relu=in_relu)
         return dw
     gemm_nt(B=1, M=Cout, N=Cin * k * k, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0,
             b_ss=xbs, ldb=0, c=dw, c_bs=0, ldc=Cin * k * k, precision=precision,

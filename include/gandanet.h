@@ -112,6 +112,8 @@ typedef struct gd_gemm_nt_desc {
     /* B as im2col rows (im2col == 1): n = c*ks*ks + tap, kk = oy*Wo + ox of an Ho x Wo output;
        element = X~[s][c][oy*stride - pad + kh][ox*stride - pad + kw], X at bm[s*b_ss + c*Hi*Wi + ...] */
     int im2col, ks, stride, pad, Hi, Wi, Ho, Wo;
+    /* optional X~ = relu?(X * in_scale[c] + in_shift[c]); the channel is c of the im2col row, or the B row n itself
+       when im2col == 0 (1x1 weight gradient with a fused BatchNorm+ReLU input) */
     const float* in_scale; const float* in_shift; int in_relu;
     /* C element (b, m, n) at c[b*c_bs + m*ldc + n]; fp32 */
     float* c; long c_bs, ldc;
