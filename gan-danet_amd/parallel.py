@@ -8,7 +8,9 @@ element fc1 gradient.  BatchNorm uses per-replica batch statistics (DDP semantic
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages beat many small ones, so
 small gradients are packed into flat buckets of ``bucket_bytes`` and big tensors (Discriminator1.fc1)
-are reduced in place, all launched asynchronously and waited on together.
+are reduced in place.  A big tensor's all-reduce is launched THE MOMENT autograd has finished its gradient
+(post-accumulate hook): fc1 sits at the end of the discriminator, so its 8.6 GB gradient is ready first and
+travels under the backward of the four conv layers; everything is waited on together in ``reduce()``.
 """
 from __future__ import annotations
 
@@ -58,13 +60,34 @@ class GradReducer:
         self.bucket_bytes = bucket_bytes
         self.group = group
         self._flat = {}
+        self._early = {}            # id(param) -> Work of an all-reduce already in flight for this backward
+        self._hooks = []
+        if is_distributed():
+            for p in self.params:
+                if isinstance(p, torch.nn.parameter.UninitializedParameter):
+                    continue
+                if p.numel() * p.element_size() >= self.bucket_bytes and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._launch_early))
+
+    def close(self) -> None:
+        """remove the gradient hooks (a parameter must be watched by ONE reducer at a time)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._early.clear()
+
+    def _launch_early(self, p: torch.nn.Parameter) -> None:
+        if p.grad is not None and id(p) not in self._early:
+            self._early[id(p)] = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
     def reduce(self) -> None:
         if not is_distributed():
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        works, buckets = [], []
+        early_ids = set(self._early.keys())           # big tensors whose all-reduce started during the backward
+        works = [self._early.pop(i) for i in early_ids]
+        grads = [p.grad for p in self.params if p.grad is not None and id(p) not in early_ids]
+        buckets = []
         cur, cur_bytes = [], 0
         for g in grads:
             nbytes = g.numel() * g.element_size()

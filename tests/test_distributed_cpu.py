@@ -47,6 +47,19 @@ def _worker(rank, world, port, tmpdir):
     red.reduce()
     grads = [p.grad.clone() / world for p in D.parameters()]   # what AdamW.grad_scale = 1/world applies
 
+    # the same with the reducer built BEFORE the backward: fc1's all-reduce must start from the post-accumulate hook
+    # (during the backward), the rest in reduce(); identical result
+    red.close()
+    for p in D.parameters():
+        p.grad = None
+    red2 = GradReducer(D.parameters(), bucket_bytes=64 << 10)
+    OF.bce_with_logits(D(tgt[sl]), torch.ones(sl.stop - sl.start, 1)).backward()
+    assert len(red2._early) >= 1, "no early all-reduce was launched from the gradient hook"
+    red2.reduce()
+    assert not red2._early
+    for p, g in zip(D.parameters(), grads):
+        assert torch.allclose(p.grad / world, g, rtol=1e-6, atol=1e-8)
+
     # single-process reference: mean over the two shards' gradients
     D2 = OM.Discriminator1()
     with torch.no_grad():
