@@ -193,8 +193,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gd_conv_desc
 
 }  // namespace
 
+// output-channel tile: 64 or 128, whichever pads M least; with a single 32-channel chunk of input (dense-layer data
+// gradients, K = 24) the kernel is staging / store bound, not MFMA bound, and the wide tile stages the patch fewer times
+static inline int pick_bm(int M, int Ck) {
+    if (Ck <= CK && M > 64) return 128;
+    return (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+}
+
 extern "C" size_t gd_conv3x3_ws_bytes(int M, int Ck) {
-    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const int bm = pick_bm(M, Ck);
     const long mtiles = (M + bm - 1) / bm, nchunks = (Ck + CK - 1) / CK;
     return (size_t)(mtiles * bm * nchunks * CK * 9 * 2);
 }
@@ -218,7 +225,7 @@ extern "C" int gd_conv3x3(const gd_conv_desc* dp, void* ws, size_t ws_bytes, voi
     GD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr), "gd_conv3x3: in_scale/in_shift must come together");
     GD_CHECK_ARG(ws_bytes >= gd_conv3x3_ws_bytes(d.M, d.Ck), "gd_conv3x3: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int bm = (d.M <= 64 || (d.M % 128 != 0 && d.M % 128 <= 64)) ? 64 : 128;
+    const int bm = pick_bm(d.M, d.Ck);
     const int mtiles = (d.M + bm - 1) / bm, nchunks = (d.Ck + CK - 1) / CK;
     const long total = (long)mtiles * nchunks * 9 * bm * CK;
     {
@@ -435,7 +442,7 @@ extern "C" int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int trans
     GD_CHECK_ARG(w && ws && Cout > 0 && Cin > 0, "gd_conv3x3_nhwc_pack: bad arguments");
     const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
     GD_CHECK_ARG(ws_bytes >= gd_conv3x3_ws_bytes(M, K), "gd_conv3x3_nhwc_pack: workspace too small");
-    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const int bm = pick_bm(M, K);
     const int mtiles = (M + bm - 1) / bm, nchunks = (K + CK - 1) / CK;
     const long total = (long)mtiles * nchunks * 9 * bm * CK;
     int blocks = (int)((total + 255) / 256);
@@ -457,7 +464,7 @@ extern "C" int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bi
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
     a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
     a.H = H; a.W = W; a.K = K; a.M = M; a.relu = relu;
-    const int bm = (M <= 64 || (M % 128 != 0 && M % 128 <= 64)) ? 64 : 128;
+    const int bm = pick_bm(M, K);
     const int mtiles = (M + bm - 1) / bm;
     a.nchunks = (K + CK - 1) / CK;
     a.tiles_x = (W + TW - 1) / TW;
