@@ -11,7 +11,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgandanet_hip.so")
 
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2   # PREC_FP16: fp16 operands in the fused PAM kernels, bf16 elsewhere
+PAM_BWD_K64_ATOMIC, PAM_BWD_K64_PARTS, PAM_BWD_K32_PARTS, PAM_BWD_TWO_KERNEL = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 
 c_fp = C.c_void_p  # device pointers travel as integers
@@ -91,9 +92,9 @@ SIGNATURES = {
     "gd_tv": (_i, [_p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "gd_ssim": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "gd_adamw": (_i, [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f, _p]),
-    "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
-    "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
-    "gd_pam_dq_part_bytes": (_sz, [_i]),
+    "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
+    "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "gd_pam_bwd_scratch_bytes": (_sz, [_i, _i]),
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -112,6 +113,7 @@ SIGNATURES = {
     "gd_chan_maxmean_fwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "gd_chan_maxmean_bwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "gd_pack_16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
 }
 
 _lib = None

@@ -23,33 +23,15 @@
 //   alternative, a query-parallel kernel that recomputes S and dP.)
 #include <stdlib.h>
 
-#include "common.h"
-#include "tile_mma.h"
+#include "pam_common.h"
 #include "../../include/gandanet.h"
 
 namespace {
 
-using gd::acc_row;
-using gd::bf16x8_native_t;
+using namespace pam;
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // staging registers: first-class vectors, never
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));   // demoted to scratch like arrays of uint4 structs
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-
-__device__ __forceinline__ f32x16_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_native_t, a),
-                                                   __builtin_bit_cast(bf16x8_native_t, b), c, 0, 0, 0);
-}
-
-// registers 8s..8s+7 of a 32x32 accumulator -> the bf16 fragment of k-step s (k = accumulator ROW index,
-// element j of lane half h <-> row 16s + 8(j>>2) + 4h + (j&3))
-__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int s) {
-    const u32x4_t w = {gd_pack_bf2(a[8 * s + 0], a[8 * s + 1]), gd_pack_bf2(a[8 * s + 2], a[8 * s + 3]),
-                       gd_pack_bf2(a[8 * s + 4], a[8 * s + 5]), gd_pack_bf2(a[8 * s + 6], a[8 * s + 7])};
-    return __builtin_bit_cast(bf16x8_t, w);
-}
+__device__ __forceinline__ f32x16_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) { return mfma16<false>(a, b, c); }
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int s) { return pam::pack_frag<false>(a, s); }
 
 // =====================================================================================================
 // forward
@@ -68,7 +50,7 @@ constexpr int D_KROWCH = 5;                 // 16-byte chunks per K row (80 B)
 // KT keys per staged tile (64 or 128: fewer barriers and DMA issue rounds per key, more independent work per wave)
 // ONES: the packed V carries a row of ones in its last padded channel (Cp - 1), so the softmax denominator is
 // accumulated by the same MFMAs as O (it is row 31 of the last channel tile) instead of 1 VALU add per element
-template <int CT, int NW, int KT, bool ONES>
+template <int CT, int NW, int KT, bool ONES, bool F16>
 __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned short* __restrict__ qt,
                                                             const unsigned short* __restrict__ kt,
                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
@@ -162,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 32 + r) * F_KLD + s * 16 + 8 * h);
-                sacc[sub] = mfma_bf16(kf, qf[s], sacc[sub]);
+                sacc[sub] = mfma16<F16>(kf, qf[s], sacc[sub]);
             }
         }
         if ((t + 1) * KT > N) {   // wave-uniform: only the last tile masks padded keys
@@ -181,10 +163,22 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
         float lsum = 0.f;
         bf16x8_t pf[NSUB][2];     // P^T tile as the B operand of O^T += V P^T (accumulator-as-operand)
         if (t == 0 || __any(mloc > 0.f)) {
-            // new maximum, rounded UP to bf16 so that it survives the trip through the Q fragment exactly
+            // new maximum, rounded UP to the operand type (bf16 / fp16) so that it survives the trip through the Q fragment exactly
             const float want = m + (t == 0 ? mloc : fmaxf(mloc, 0.f));
-            const unsigned int wb = __builtin_bit_cast(unsigned int, want);
-            const float m_new = __builtin_bit_cast(float, want > 0.f ? (wb + 0xFFFFu) & 0xFFFF0000u : wb & 0xFFFF0000u);
+            float m_new;
+            unsigned short m_neg16;          // -m_new in the operand type
+            if constexpr (F16) {
+                // fp16: round to nearest, then step one ulp towards +inf if that fell below `want`
+                _Float16 hm = (_Float16)want;
+                unsigned short hb = __builtin_bit_cast(unsigned short, hm);
+                if ((float)hm < want) hb = (hb & 0x8000u) ? (unsigned short)(hb - 1) : (unsigned short)(hb + 1);
+                m_new = (float)__builtin_bit_cast(_Float16, hb);
+                m_neg16 = hb ^ 0x8000u;
+            } else {
+                const unsigned int wb = __builtin_bit_cast(unsigned int, want);
+                m_new = __builtin_bit_cast(float, want > 0.f ? (wb + 0xFFFFu) & 0xFFFF0000u : wb & 0xFFFF0000u);
+                m_neg16 = (unsigned short)(__builtin_bit_cast(unsigned int, -m_new) >> 16);
+            }
             const float shift = m_new - m;
             if (t != 0) {
                 const float alpha = gd_exp2_fast(-shift);
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                     for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
             }
             m = m_new;
-            if (h) qf[1][7] = (short)(__builtin_bit_cast(unsigned int, -m_new) >> 16);   // d = 31 lives in lane half 1
+            if (h) qf[1][7] = (short)m_neg16;   // d = 31 lives in lane half 1
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
@@ -203,8 +197,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                     sacc[sub][e] = gd_exp2_fast(sacc[sub][e] - shift);
                     if (!ONES) lsum += sacc[sub][e];
                 }
-                pf[sub][0] = pack_frag(sacc[sub], 0);
-                pf[sub][1] = pack_frag(sacc[sub], 1);
+                pf[sub][0] = pam::pack_frag<F16>(sacc[sub], 0);
+                pf[sub][1] = pam::pack_frag<F16>(sacc[sub], 1);
             }
         } else {
 #pragma unroll
@@ -214,8 +208,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                     sacc[sub][e] = gd_exp2_fast(sacc[sub][e]);
                     if (!ONES) lsum += sacc[sub][e];
                 }
-                pf[sub][0] = pack_frag(sacc[sub], 0);
-                pf[sub][1] = pack_frag(sacc[sub], 1);
+                pf[sub][0] = pam::pack_frag<F16>(sacc[sub], 0);
+                pf[sub][1] = pam::pack_frag<F16>(sacc[sub], 1);
             }
         }
         if (!ONES) {
@@ -236,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                 vf[ct] = *reinterpret_cast<const bf16x8_t*>(Vs + (ct * 32 + r) * VLD + sub * 32 + s2 * 16 + 8 * h);
             __builtin_amdgcn_sched_group_barrier(0x100, CT, 0);   // DS reads
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) o[ct] = mfma_bf16(vf[ct], pf[sub][s2], o[ct]);
+            for (int ct = 0; ct < CT; ++ct) o[ct] = mfma16<F16>(vf[ct], pf[sub][s2], o[ct]);
             __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);   // MFMAs
         }
     }
@@ -261,7 +255,6 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     }
 }
 
-constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
 
 // =====================================================================================================
 // backward, part 1c: dK^T / dV^T, transpose-read variant.  Only Q [i][d] and dO [i][c] are staged per query
@@ -271,37 +264,6 @@ constexpr int B_QLD = 40;   // Q tile rows [i][32 d] (80 B): 16-B reads
 // NW = 4 (without dQ): 4 waves per workgroup and two independent workgroups per CU: their phases drift apart, so one's MFMA
 // segments overlap the other's softmax / staging segments instead of all eight waves meeting at one barrier.
 // =====================================================================================================
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ s16x4_t lds_tr16(const unsigned short* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-}
-// A fragment (row = column c of X, k = accumulator-row-ordered query index) of k-step s from X[i][c] (LDS, ld):
-// element j of lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)
-__device__ __forceinline__ bf16x8_t read_tr_frag(const unsigned short* X, int ld, int s, int ccol, int lane) {
-    const int li = lane & 15, hh = lane >> 5;
-    const unsigned short* p = X + (16 * s + 4 * hh + (li >> 2)) * ld + ccol + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
-    const s16x4_t lo = lds_tr16(p);             // queries 16s + 4h + 0..3
-    const s16x4_t hi = lds_tr16(p + 8 * ld);    // queries 16s + 8 + 4h + 0..3
-    const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return f;
-}
-
-// dO tile image: rows of DOLD = CP + 32 elements (448 B at CP = 192: 28 sixteen-byte units, 28 = 12 mod 16) with the
-// 16-byte chunk index XOR-swizzled by (row >> 2) & 3.  Both ways the tile is read are then bank-conflict free:
-//   plain 16-byte reads, 16 rows x one chunk per pass : units {0,12,8,4} (row & 3) + {c^0..c^3} (row >> 2) -> 16 distinct;
-//   transpose reads, 4 rows x 4 chunks per 32-lane pass: units {0,12,8,4} + {g..g+3}              -> 16 distinct
-// (with plain 400-byte rows the transpose reads ran 2-way conflicted on half the banks: PMC SQ_LDS_BANK_CONFLICT).
-__device__ __forceinline__ int do_off(int row, int chunk, int ld) { return row * ld + ((chunk ^ ((row >> 2) & 3)) << 3); }
-__device__ __forceinline__ bf16x8_t read_tr_frag_sw(const unsigned short* X, int ld, int s, int ct, int lane) {
-    const int li = lane & 15, hh = lane >> 5;
-    const int row = 16 * s + 4 * hh + (li >> 2);
-    const int chunk = 4 * ct + 2 * ((lane >> 4) & 1) + ((li & 3) >> 1), sub = 4 * (li & 1);
-    const s16x4_t lo = lds_tr16(X + do_off(row, chunk, ld) + sub);          // queries 16s + 4h + 0..3
-    const s16x4_t hi = lds_tr16(X + do_off(row + 8, chunk, ld) + sub);      // queries 16s + 8 + 4h + 0..3
-    const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return f;
-}
-
 // DQ: also emit this key block's contribution to dQ.  dS is already in registers here; recomputing S and dP in a
 // second query-parallel kernel (pam_bwd_dq_kernel) costs 14 MFMAs per 32x32 tile, turning the tile around through
 // 2.5 KB of wave-private LDS and 2 more MFMAs does not: each wave transposes its dS tile (LDS transpose read),
@@ -701,8 +663,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
     }
 
 extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
-                                int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
-                                float* o_attn, float* lse, void* stream) {
+                                int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out,
+                                long out_bs, float* o_attn, float* lse, void* stream) {
     GD_CHECK_ARG(qt && kt && v && gamma && x && out && o_attn && lse, "gd_pam_flash_fwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
@@ -715,55 +677,81 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     const dim3 grid(Npad / 256, B), block(512);
     hipStream_t s = (hipStream_t)stream;
 #define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse
-    if (v_ones) {
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true>), grid, block, 0, s, PAM_FWD_ARGS));
+    if (f16) {
+        if (v_ones) {
+            PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true, true>), grid, block, 0, s, PAM_FWD_ARGS));
+        } else {
+            PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, false, true>), grid, block, 0, s, PAM_FWD_ARGS));
+        }
+    } else if (v_ones) {
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true, false>), grid, block, 0, s, PAM_FWD_ARGS));
     } else {
-        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, false>), grid, block, 0, s, PAM_FWD_ARGS));
+        PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, false, false>), grid, block, 0, s, PAM_FWD_ARGS));
     }
 #undef PAM_FWD_ARGS
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-// key block of the fused backward: 8 waves = 256 keys per workgroup (default; 18.0 ms at B=4, C=184) or 4 waves = 128
-// keys, two workgroups per CU (GD_PAM_DKV_NW=4; 18.9 ms and twice the dQ parts)
-static int pam_dkv_waves() {
-    static const int nw = getenv("GD_PAM_DKV_NW") ? atoi(getenv("GD_PAM_DKV_NW")) : 8;
-    return nw == 4 ? 4 : 8;
+extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int nb, float* dqn, void* stream) {
+    hipLaunchKernelGGL(pam_dq_reduce_kernel, dim3(Npad / 64, nb), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)part, KB, Npad, dqn);
 }
-extern "C" size_t gd_pam_dq_part_bytes(int Npad) {
-    return (size_t)(Npad / (32 * pam_dkv_waves())) * (size_t)Npad * 32 * sizeof(unsigned short);
+
+// pam_bwd64.hip
+extern "C" size_t gd_pam_bwd64_scratch_bytes(int Npad, int deterministic);
+extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
+                                  const float* lse, const float* delta, int nb, int N, int Npad, int Cp, int f16,
+                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, void* scratch,
+                                  void* stream);
+
+// Backward forms (gandanet.h GD_PAM_BWD_*):
+//   0 K64_ATOMIC : 4 waves x 64 keys, one wave per SIMD, fp32 atomics for dQ            (default, fastest)
+//   1 K64_PARTS  : the same kernel, dQ as bf16 parts per 256-key block + streaming sum   (bitwise reproducible)
+//   2 K32_PARTS  : round-1 kernel, 8 waves x 32 keys, bf16 parts                         (bitwise reproducible)
+//   3 TWO_KERNEL : dK/dV kernel + query-parallel dQ kernel recomputing S and dP          (no scratch)
+extern "C" size_t gd_pam_bwd_scratch_bytes(int Npad, int form) {
+    if (form == 0 || form == 1) return gd_pam_bwd64_scratch_bytes(Npad, form == 1);
+    if (form == 2) return (size_t)(Npad / 256) * (size_t)Npad * 32 * sizeof(unsigned short);
+    return 0;
+}
+
+// GD_PAM_K64_VREG=2: V fragments of both key tiles of a wave in registers (default 1: one in registers, one in LDS)
+static int pam_k64_vreg() {
+    static const int v = getenv("GD_PAM_K64_VREG") ? atoi(getenv("GD_PAM_K64_VREG")) : 1;
+    return v == 2 ? 2 : 1;
 }
 
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
-                                const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn,
-                                float* dkn, float* dv, void* dq_part, size_t dq_part_bytes, void* stream) {
+                                const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
+                                float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream) {
     GD_CHECK_ARG(qt && kt && kn && vt && dot_ && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
+    GD_CHECK_ARG(form >= 0 && form <= 3, "gd_pam_flash_bwd: form must be 0..3");
+    GD_CHECK_ARG(!f16 || form <= 1, "gd_pam_flash_bwd: fp16 operands need form 0 or 1");
     hipStream_t s = (hipStream_t)stream;
     const unsigned short *q = (const unsigned short*)qt, *k = (const unsigned short*)kt, *kT = (const unsigned short*)kn;
     const unsigned short *v = (const unsigned short*)vt, *dO = (const unsigned short*)dot_;
-    const size_t per_image = gd_pam_dq_part_bytes(Npad);
-    if (dq_part && dq_part_bytes >= per_image) {
-        // fused: the key-parallel kernel also emits bf16 dQ parts per key block, summed by a streaming kernel; the
-        // batch is walked in slices that fit the caller's scratch buffer
-        const int slice = (int)(dq_part_bytes / per_image < (size_t)B ? dq_part_bytes / per_image : (size_t)B);
-        const int nw_env = pam_dkv_waves();
+    const size_t per_image = gd_pam_bwd_scratch_bytes(Npad, form);
+    if (form <= 2) {
+        GD_CHECK_ARG(scratch && scratch_bytes >= per_image, "gd_pam_flash_bwd: scratch smaller than gd_pam_bwd_scratch_bytes (one image)");
+        // the batch is walked in slices that fit the caller's scratch buffer
+        const int slice = (int)(scratch_bytes / per_image < (size_t)B ? scratch_bytes / per_image : (size_t)B);
         for (int b0 = 0; b0 < B; b0 += slice) {
             const int nb = B - b0 < slice ? B - b0 : slice;
             const long o32 = (long)b0 * Npad * 32, oc = (long)b0 * Npad * Cp, on = (long)b0 * N;
-            if (nw_env == 8) {
+            if (form <= 1) {
+                const int rcode = gd_pam_bwd64_slice(q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on, nb, N,
+                                                     Npad, Cp, f16, pam_k64_vreg(), form == 1, dqn + o32, dkn + o32, dv + oc,
+                                                     scratch, stream);
+                if (rcode) return rcode;
+            } else {
                 PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true, 8>), dim3(Npad / 256, nb), dim3(512), 0, s,
                                                              q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
-                                                             N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
-            } else {
-                PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true>), dim3(Npad / 128, nb), dim3(256), 0, s,
-                                                             q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on,
-                                                             N, Npad, dkn + o32, dv + oc, (unsigned short*)dq_part));
+                                                             N, Npad, dkn + o32, dv + oc, (unsigned short*)scratch));
+                gd_pam_dq_reduce_launch(scratch, Npad / 256, Npad, nb, dqn + o32, stream);
             }
-            hipLaunchKernelGGL(pam_dq_reduce_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const unsigned short*)dq_part,
-                               Npad / (nw_env == 8 ? 256 : 128), Npad, dqn + o32);
         }
         GD_LAUNCH_CHECK();
         return 0;

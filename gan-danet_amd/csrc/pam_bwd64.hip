@@ -1,0 +1,491 @@
+// PAM backward, key-parallel, ONE wave per SIMD (generator.py:115-122 under autograd).
+//
+// A workgroup = 4 waves = 256 keys of one image; each wave owns 64 keys (two 32-key tiles) and keeps their dV^T
+// (64 x Cp) and dK^T (64 x 32) in accumulators for the whole sweep over the queries -- the 512-register shape (one
+// wave per SIMD, accumulators in the AGPR half).  Per 32-query tile a wave issues 60 MFMAs:
+//     S = Q K^T (2+2), dP = dO V^T (2 x 2CT), dV^T += dO^T P (2 x 2CT), dK^T += Q^T dS (2+2), dQ^T part (4)
+// and every A fragment read from LDS (Q rows, dO rows, dO^T / Q^T transpose reads) feeds TWO MFMAs, one per key tile:
+// half the LDS bytes per MFMA of the 32-keys-per-wave kernel (pam_bwd_dkv3_kernel), and one barrier per 60 MFMAs.
+//   * key on the lane: S and dP come out [query rows][key lanes], so P and dS are directly the B operands of the
+//     dV^T / dK^T products (accumulator-as-operand); -lse*log2e and -delta enter as the accumulator input.
+//   * Q [i][d], dO [i][c] and the row constants of a query tile arrive by LDS-DMA (global_load_lds_dwordx4) into a
+//     3-slot ring, two tiles ahead, behind counted vmcnt waits and a raw s_barrier (one per tile).
+//   * V rows of the wave's keys: VREG of its two key tiles are held in registers as B fragments, the rest in LDS.
+//   * dQ: the wave's dS tiles are turned around through wave-private LDS (transpose read), multiplied by its K^T
+//     rows (4 MFMAs sum over its 64 keys), the four waves' fp32 parts are exchanged through LDS and
+//       ATOMIC : added with fp32 atomics (256 contiguous bytes per wave-instruction) into dq_acc (B, Npad, 32);
+//                key blocks start their sweep at different query tiles so that adds spread over many rows;
+//       !ATOMIC: stored as one bf16 part per key block (deterministic; pam_dq_reduce_kernel sums them).
+// No masks: padded queries carry -1e30 as their -lse (P = 0), padded keys only touch padded outputs (the packs are
+// zero filled).
+#include "pam_common.h"
+#include "../../include/gandanet.h"
+
+namespace {
+
+using namespace pam;
+
+// rc (B, Npad/32, 64): per 32-query tile [32 x -lse*log2e][32 x -delta]; padded queries: -1e30 / 0
+__global__ __launch_bounds__(256) void pam_rowconst_kernel(const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          int N, int Npad, float* __restrict__ rc) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    float a = -1e30f, d = 0.f;
+    if (i < N) {
+        a = -lse[(long)b * N + i] * LOG2E;
+        d = -delta[(long)b * N + i];
+    }
+    float* t = rc + ((long)b * (Npad / 32) + (i >> 5)) * 64 + (i & 31);
+    t[0] = a;
+    t[32] = d;
+}
+
+// dq_acc (B, Npad, 32) fp32 [query][d]  ->  dqn (B, 32, Npad) [d][query]
+__global__ __launch_bounds__(256) void pam_dq_transpose_kernel(const float* __restrict__ acc, int Npad,
+                                                              float* __restrict__ dqn) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.y, i0 = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+        const int q = idx >> 5, d = idx & 31;
+        tile[q][d] = acc[((long)b * Npad + i0 + q) * 32 + d];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
+        const int d = idx >> 6, q = idx & 63;
+        dqn[((long)b * 32 + d) * Npad + i0 + q] = tile[q][d];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- transpose reads as inline asm -------------------------------------------------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr16 BUILTIN whenever an LDS-DMA is in flight
+// (its LDS-DMA alias tracking has no scope information for that intrinsic), which would drain the DMA ring and the dQ
+// atomics every tile.  The asm forms are invisible to that pass; their results are handed to the compiler only through
+// tr_wait(), which names them as read-write operands (guide 5.7 form ii): no consumer can be scheduled above the wait.
+// LDS returns in order, so lgkmcnt(N) with N = the transpose reads issued AFTER the batch being waited for is exact
+// when nothing else was issued in between and merely stricter when the compiler slipped LDS operations of its own in.
+struct TrFrag2 {          // the two A fragments (k-steps s = 0, 1) of one 32-row operand tile
+    s16x4_t lo0, hi0, lo1, hi1;
+};
+__device__ __forceinline__ unsigned int lds_addr(const void* p) {
+    return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4_t tr_issue(unsigned int addr) {
+    s16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// lo / hi: byte addresses of the lane's first row group and of the one 8 rows below; STEP: bytes between k-steps
+template <int OFF, int STEP>
+__device__ __forceinline__ TrFrag2 tr_issue2(unsigned int lo, unsigned int hi) {
+    TrFrag2 f;
+    f.lo0 = tr_issue<OFF>(lo);
+    f.hi0 = tr_issue<OFF>(hi);
+    f.lo1 = tr_issue<OFF + STEP>(lo);
+    f.hi1 = tr_issue<OFF + STEP>(hi);
+    return f;
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(TrFrag2& f) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.lo0), "+v"(f.hi0), "+v"(f.lo1), "+v"(f.hi1) : "n"(N) : "memory");
+}
+__device__ __forceinline__ bf16x8_t tr_frag(const s16x4_t& lo, const s16x4_t& hi) {
+    const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return f;
+}
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int CT, bool F16, int VREG, bool ATOMIC>
+__global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
+    const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
+    const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ rc,
+    int Npad, float* __restrict__ dkn, float* __restrict__ dv, void* __restrict__ dq_out) {
+    constexpr int CP = CT * 32;
+    constexpr int DOLD = CP + 32;                  // dO rows, chunk-swizzled (do_off)
+    constexpr int DROWCH = DOLD / 8;               // 16-byte chunks per dO row
+    constexpr int QCH = 192;                       // Q region: 32 rows x 5 chunks (80-byte rows) = 160, padded to 3 pieces
+    constexpr int DCH = 32 * DROWCH;               // = 128 (CT + 1): a whole number of 64-chunk pieces
+    constexpr int SLOT_CH = QCH + DCH + 64;        // + one full DMA piece of row constants (16 chunks used: this tile's)
+    constexpr int SLOT = SLOT_CH * 8;              // ring slot, in 16-bit elements
+    constexpr int NPIECE = 3 + DCH / 64 + 1;
+    constexpr int PPW = (NPIECE + 3) / 4;          // DMA wave-instructions per wave and tile (every wave issues PPW)
+    constexpr int NSLOT = 3;
+    constexpr int XLD = 36;                        // dS^T rows: 72 bytes (conflict-free 8-byte writes / transpose reads)
+    constexpr int XW = 2 * 32 * XLD;               // per wave: the two key tiles' dS^T
+    constexpr int QXLD = 36;                       // dQ exchange rows, floats
+    constexpr int DLD = CP + 8;                    // V rows in LDS
+    constexpr int OFF_X = NSLOT * SLOT;
+    constexpr int OFF_XQ = OFF_X + 4 * XW;
+    constexpr int XQ_BUF = 4 * 32 * QXLD;          // floats per exchange buffer
+    constexpr int OFF_V = OFF_XQ + 2 * XQ_BUF * 2;
+    constexpr int VLDS = 2 - VREG;                 // key tiles per wave whose V rows live in LDS
+    constexpr int V_ELEMS = 4 * VLDS * 32 * DLD;
+    constexpr int AOPS = ATOMIC ? 4 : 1;           // VMEM operations of one dQ hand-over per wave
+    static_assert(DCH % 64 == 0 && (OFF_X % 8) == 0 && (OFF_XQ % 8) == 0 && (OFF_V % 8) == 0, "LDS carve");
+    static_assert((OFF_V + V_ELEMS) * 2 <= 163840, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned short lds[OFF_V + (V_ELEMS ? V_ELEMS : 8)];   // the ONLY LDS object
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, kb = blockIdx.x;
+    const int j0 = kb * 256 + wave * 64;
+    const long nb = (long)b * Npad;
+    const int nqt = Npad / 32;
+
+    // ---- this wave's key-side operands (registers for the whole sweep) ----
+    bf16x8_t kfB[2][2], knA[2][2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kfB[k2][s] = *reinterpret_cast<const bf16x8_t*>(kt + (nb + j0 + 32 * k2 + r) * 32 + s * 16 + 8 * h);
+            // K^T rows as the A operand of dQ^T[d][i] += K^T[d][j] dS^T[j][i] (kn is perm16: one 16-byte read is an
+            // accumulator-row-ordered k-step)
+            knA[k2][s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + 32 * k2 + s * 16 + 8 * h);
+        }
+    bf16x8_t vB[VREG > 0 ? VREG : 1][2 * CT];
+#pragma unroll
+    for (int k2 = 0; k2 < VREG; ++k2)
+#pragma unroll
+        for (int s = 0; s < 2 * CT; ++s)
+            vB[k2][s] = *reinterpret_cast<const bf16x8_t*>(vt + (nb + j0 + 32 * k2 + r) * CP + s * 16 + 8 * h);
+    unsigned short* Vw = lds + OFF_V + wave * (VLDS * 32 * DLD);   // wave-private V rows (key tiles VREG..1)
+    if constexpr (VLDS > 0) {
+        const unsigned short* vsrc = vt + (nb + j0 + 32 * VREG) * CP;
+        for (int c = lane; c < VLDS * 32 * (CP / 8); c += 64) {
+            const int row = c / (CP / 8), ch = c - row * (CP / 8);
+            *reinterpret_cast<u32x4_t*>(Vw + row * DLD + ch * 8) = *reinterpret_cast<const u32x4_t*>(vsrc + (long)row * CP + ch * 8);
+        }
+    }
+    // dQ exchange buffers start at zero: iteration 0 hands over an all-zero "previous tile"
+    {
+        float* xq = reinterpret_cast<float*>(lds + OFF_XQ);
+        for (int c = tid; c < 2 * XQ_BUF; c += 256) xq[c] = 0.f;
+    }
+
+    // ---- DMA plan: byte offset of this lane's chunk inside the tile's Q / dO / row-constant source ----
+    unsigned int voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        int piece = wave + 4 * i;
+        if (piece >= NPIECE) piece = NPIECE - 2;           // filler: re-fetch a dO piece (same bytes, same place)
+        const int c = piece * 64 + lane;
+        if (piece < 3) {
+            const int row = c / 5, part = c - row * 5;
+            voff[i] = c < 160 ? (unsigned int)(row * 32 + (part < 4 ? part : 3) * 8) * 2u : 0u;
+        } else if (piece < NPIECE - 1) {
+            const int c2 = c - QCH;
+            const int row = c2 / DROWCH, sl = c2 - row * DROWCH;
+            const int chunk = sl < CP / 8 ? (sl ^ ((row >> 2) & 3)) : 0;
+            voff[i] = (unsigned int)(row * CP + chunk * 8) * 2u;
+        } else {
+            voff[i] = (unsigned int)lane * 16u;             // 1 KiB = this tile's constants + the next three tiles' (unused)
+        }
+    }
+    auto dma_tile = [&](int t, int slot) {
+        const char* qb = reinterpret_cast<const char*>(qt + (nb + (long)t * 32) * 32);
+        const char* db = reinterpret_cast<const char*>(dot_ + (nb + (long)t * 32) * CP);
+        const char* rb = reinterpret_cast<const char*>(rc + ((long)b * nqt + t) * 64);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int piece = wave + 4 * i;
+            if (piece >= NPIECE) piece = NPIECE - 2;
+            unsigned short* dst = lds + slot * SLOT + piece * 512;     // wave-uniform piece base
+            const char* base = piece < 3 ? qb : piece < NPIECE - 1 ? db : rb;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[i]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16_t dvacc[2][CT], dkacc[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkacc[k2][e] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dvacc[k2][ct][e] = 0.f;
+    }
+
+    // key blocks that share an XCD (equal kb % 8 under round-robin placement) start close together (L2 reuse of the
+    // streamed Q / dO tiles), 4 tiles apart (atomic adds of neighbours land in different rows); the 8 groups start an
+    // eighth of the sweep apart
+    int tcur = ATOMIC ? (int)(((long)(kb & 7) * (nqt / 8) + (long)(kb >> 3) * 4) % nqt) : 0;
+    auto next_tile = [&](int t) { return t + 1 == nqt ? 0 : t + 1; };
+    int tprev = tcur == 0 ? nqt - 1 : tcur - 1;
+
+    unsigned short* Xw = lds + OFF_X + wave * XW;
+    // per-lane LDS offsets (16-bit elements), fixed for the whole sweep
+    const int li = lane & 15, g4 = (lane >> 4) & 1;
+    const int swz_r = (r >> 2) & 3;
+    const int off_qrow = r * B_QLD + 8 * h;                                   // Q row fragment: + 16 s
+    const int off_do_e = r * DOLD + ((h ^ swz_r) << 3);                       // dO row fragment, even k-step s: + 32 (s >> 1)
+    const int off_do_o = r * DOLD + (((2 + h) ^ swz_r) << 3);                 //                  odd k-step
+    const int c2 = 2 * g4 + ((li & 3) >> 1);
+    const int off_trd_lo = (4 * h + (li >> 2)) * DOLD + ((c2 ^ h) << 3) + 4 * (li & 1);            // dO^T: + 16 s DOLD + 32 ct
+    const int off_trd_hi = (4 * h + (li >> 2) + 8) * DOLD + ((c2 ^ (h + 2)) << 3) + 4 * (li & 1);  //   rows + 8: swizzle h + 2
+    const int off_trq = (4 * h + (li >> 2)) * B_QLD + 16 * g4 + 4 * (li & 3);                      // Q^T: + 16 s B_QLD (+ 8 B_QLD)
+    const unsigned short* x_tr = Xw + (4 * h + (li >> 2)) * XLD + 16 * g4 + 4 * (li & 3);          // dS^T: + 32 k2 XLD + 16 s XLD
+    unsigned short* x_wr = Xw + r * XLD + 4 * h;
+    const unsigned short* v_rows = Vw + r * DLD + 8 * h;
+    float* xq_base = reinterpret_cast<float*>(lds + OFF_XQ);
+
+    // hand the previous tile's dQ over: sum the four waves' fp32 parts, then atomics / one bf16 part store
+    auto dq_handover = [&](int buf, int tq) {
+        const float* xr = xq_base + buf * XQ_BUF;
+        if constexpr (ATOMIC) {
+            float* acc = reinterpret_cast<float*>(dq_out) + (nb + (long)tq * 32) * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 8 * wave + 2 * k + h;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += xr[w * 32 * QXLD + i * QXLD + r];
+                atomicAdd(acc + i * 32 + r, v);      // one wave-instruction = two adjacent 128-byte rows
+            }
+        } else {
+            unsigned short* part = reinterpret_cast<unsigned short*>(dq_out) + (((long)b * (Npad / 256) + kb) * Npad + (long)tq * 32) * 32;
+            const int i = 8 * wave + (lane >> 3), d4 = (lane & 7) * 4;
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += *reinterpret_cast<const f32x4_t*>(xr + w * 32 * QXLD + i * QXLD + d4);
+            const u32x2_t o = {pack2<false>(a[0], a[1]), pack2<false>(a[2], a[3])};
+            *reinterpret_cast<u32x2_t*>(part + i * 32 + d4) = o;
+        }
+    };
+
+    {
+        dma_tile(tcur, 0);
+        dma_tile(next_tile(tcur), 1);
+    }
+    int tpf = next_tile(next_tile(tcur));   // next tile to prefetch
+
+    for (int it = 0; it < nqt; ++it) {
+        // tile `it` landed: this wave's pieces by its own counted wait, the other waves' by the barrier behind it.
+        // Younger VMEM operations than DMA(it): [hand-over(it-3)] DMA(it+1) [hand-over(it-2)]
+        if (it < 2) wait_vmcnt<PPW>();
+        else wait_vmcnt<PPW + 2 * AOPS>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
+        __builtin_amdgcn_s_barrier();
+        const int slot = it % NSLOT;
+        dma_tile(tpf, (it + 2) % NSLOT);     // slot of tile it-1: every wave is past its reads (it is past this barrier)
+        tpf = next_tile(tpf);
+        dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
+
+        // every LDS address below = (ring slot base) + (per-lane offset fixed for the whole sweep) + (compile-time
+        // immediate): the XOR swizzle of the dO image only touches the low two chunk bits, so it folds into the
+        // per-lane part
+        const unsigned short* Qs = lds + slot * SLOT;
+        const unsigned short* dOs = Qs + QCH * 8;
+        const float* RC = reinterpret_cast<const float*>(dOs + DCH * 8);
+        const unsigned short* q_rows = Qs + off_qrow;
+        const unsigned short* do_rows_e = dOs + off_do_e;
+        const unsigned short* do_rows_o = dOs + off_do_o;
+        const unsigned short* do_tr_lo = dOs + off_trd_lo;
+        const unsigned short* do_tr_hi = dOs + off_trd_hi;
+        const unsigned short* q_tr = Qs + off_trq;
+
+        f32x16_t sacc[2], dpacc[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(RC + 8 * g + 4 * h);
+            const f32x4_t d = *reinterpret_cast<const f32x4_t*>(RC + 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sacc[0][4 * g + e] = a[e];
+                sacc[1][4 * g + e] = a[e];
+                dpacc[0][4 * g + e] = d[e];
+                dpacc[1][4 * g + e] = d[e];
+            }
+        }
+        // S = Q K^T - lse (log2 domain)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(q_rows + s * 16);
+            sacc[0] = mfma16<F16>(qa, kfB[0][s], sacc[0]);
+            sacc[1] = mfma16<F16>(qa, kfB[1][s], sacc[1]);
+        }
+        // dP = dO V^T - delta
+#pragma unroll
+        for (int s = 0; s < 2 * CT; ++s) {
+            const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(((s & 1) ? do_rows_o : do_rows_e) + (s >> 1) * 32);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                bf16x8_t vb;
+                if (k2 < VREG) vb = vB[k2 < VREG ? k2 : 0][s];
+                else vb = *reinterpret_cast<const bf16x8_t*>(v_rows + (k2 - VREG) * 32 * DLD + s * 16);
+                dpacc[k2] = mfma16<F16>(da, vb, dpacc[k2]);
+            }
+        }
+        bf16x8_t pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[k2][e] = gd_exp2_fast(sacc[k2][e]);   // P
+            pf[k2][0] = pack_frag<F16>(sacc[k2], 0);
+            pf[k2][1] = pack_frag<F16>(sacc[k2], 1);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dpacc[k2][e] *= sacc[k2][e];               // dS = P (dP - delta)
+            dsf[k2][0] = pack_frag<F16>(dpacc[k2], 0);
+            dsf[k2][1] = pack_frag<F16>(dpacc[k2], 1);
+            // dS tile [query rows][key lanes] -> X[key][query] (this lane's 16 queries are 4 runs of 4)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4_t w = __builtin_bit_cast(u32x4_t, dsf[k2][s]);
+                const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
+                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * s) = lo;
+                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * s + 8) = hi;
+            }
+        }
+        // dV^T += dO^T P, dK^T += Q^T dS, dQ^T part: all A/B fragments below come from transpose reads (element j of
+        // lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)), issued one batch (4 reads = both k-steps of one tile)
+        // ahead of the MFMAs that consume them
+        const unsigned int a_dlo = lds_addr(do_tr_lo), a_dhi = lds_addr(do_tr_hi);
+        const unsigned int a_q = lds_addr(q_tr), a_x = lds_addr(x_tr);
+        TrFrag2 fb[CT + 3];     // CT dO^T batches, Q^T, X(key tile 0), X(key tile 1)
+        fb[0] = tr_issue2<0, 16 * DOLD * 2>(a_dlo, a_dhi);
+        static_for<0, CT>([&](auto ic) {
+            constexpr int ct = decltype(ic)::value;
+            if constexpr (ct + 1 < CT) fb[ct + 1] = tr_issue2<(ct + 1) * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
+            else fb[CT] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
+            tr_wait<4>(fb[ct]);
+            const bf16x8_t a0 = tr_frag(fb[ct].lo0, fb[ct].hi0), a1 = tr_frag(fb[ct].lo1, fb[ct].hi1);
+            dvacc[0][ct] = mfma16<F16>(a0, pf[0][0], dvacc[0][ct]);
+            dvacc[1][ct] = mfma16<F16>(a0, pf[1][0], dvacc[1][ct]);
+            dvacc[0][ct] = mfma16<F16>(a1, pf[0][1], dvacc[0][ct]);
+            dvacc[1][ct] = mfma16<F16>(a1, pf[1][1], dvacc[1][ct]);
+        });
+        {   // dK^T += Q^T dS
+            fb[CT + 1] = tr_issue2<0, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
+            tr_wait<4>(fb[CT]);
+            const bf16x8_t a0 = tr_frag(fb[CT].lo0, fb[CT].hi0), a1 = tr_frag(fb[CT].lo1, fb[CT].hi1);
+            dkacc[0] = mfma16<F16>(a0, dsf[0][0], dkacc[0]);
+            dkacc[1] = mfma16<F16>(a0, dsf[1][0], dkacc[1]);
+            dkacc[0] = mfma16<F16>(a1, dsf[0][1], dkacc[0]);
+            dkacc[1] = mfma16<F16>(a1, dsf[1][1], dkacc[1]);
+        }
+        // dQ^T part of this wave's 64 keys: transpose read = the B operand (lane = query, k = key)
+        f32x16_t dqp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqp[e] = 0.f;
+        {
+            fb[CT + 2] = tr_issue2<32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
+            tr_wait<4>(fb[CT + 1]);
+            dqp = mfma16<F16>(knA[0][0], tr_frag(fb[CT + 1].lo0, fb[CT + 1].hi0), dqp);
+            dqp = mfma16<F16>(knA[0][1], tr_frag(fb[CT + 1].lo1, fb[CT + 1].hi1), dqp);
+            tr_wait<0>(fb[CT + 2]);
+            dqp = mfma16<F16>(knA[1][0], tr_frag(fb[CT + 2].lo0, fb[CT + 2].hi0), dqp);
+            dqp = mfma16<F16>(knA[1][1], tr_frag(fb[CT + 2].lo1, fb[CT + 2].hi1), dqp);
+        }
+        {
+            float* xw = xq_base + (it & 1) * XQ_BUF + wave * 32 * QXLD + r * QXLD + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t v = {dqp[4 * g], dqp[4 * g + 1], dqp[4 * g + 2], dqp[4 * g + 3]};
+                *reinterpret_cast<f32x4_t*>(xw + 8 * g) = v;
+            }
+        }
+        tprev = tcur;
+        tcur = next_tile(tcur);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dq_handover((nqt + 1) & 1, tprev);
+
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int j = j0 + 32 * k2 + r;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[k2][ct][e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[k2][e] * LN2;   // Q^T was q * log2 e
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+// scratch of one image: row constants (Npad/32 x 64 floats) + dQ accumulator (Npad x 32 floats, ATOMIC) or the bf16
+// dQ parts (Npad/256 key blocks x Npad x 32, deterministic)
+extern "C" size_t gd_pam_bwd64_scratch_bytes(int Npad, int deterministic) {
+    const size_t rcb = (size_t)Npad * 2 * sizeof(float);
+    const size_t dq = deterministic ? (size_t)(Npad / 256) * (size_t)Npad * 32 * sizeof(unsigned short)
+                                    : (size_t)Npad * 32 * sizeof(float);
+    return rcb + dq;
+}
+
+namespace {
+template <int CT, bool F16, int VREG, bool ATOMIC>
+void launch_k64(dim3 grid, hipStream_t s, const unsigned short* q, const unsigned short* k, const unsigned short* kT,
+                const unsigned short* v, const unsigned short* dO, const float* rc, int Npad, float* dkn, float* dv,
+                void* dq_out) {
+    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out);
+}
+}  // namespace
+
+extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int nb, float* dqn, void* stream);   // pam.hip
+
+// one batch slice through the 64-keys-per-wave backward; scratch holds `images` images' worth
+extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
+                                  const float* lse, const float* delta, int nb, int N, int Npad, int Cp, int f16,
+                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, void* scratch,
+                                  void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float* rc = reinterpret_cast<float*>(scratch);
+    char* dq_scr = reinterpret_cast<char*>(scratch) + (size_t)nb * Npad * 2 * sizeof(float);
+    hipLaunchKernelGGL(pam_rowconst_kernel, dim3(Npad / 256, nb), dim3(256), 0, s, lse, delta, N, Npad, rc);
+    if (!deterministic) {
+        if (hipMemsetAsync(dq_scr, 0, (size_t)nb * Npad * 32 * sizeof(float), s) != hipSuccess) {
+            gd_set_error("gd_pam_flash_bwd: hipMemsetAsync of the dQ accumulator failed");
+            return -2;
+        }
+    }
+    const dim3 grid(Npad / 256, nb);
+    const unsigned short *q = (const unsigned short*)qt, *k = (const unsigned short*)kt, *kT = (const unsigned short*)kn;
+    const unsigned short *v = (const unsigned short*)vt, *dO = (const unsigned short*)dot_;
+#define K64_ARGS grid, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr
+#define K64_CASE(CT_)                                                                                   \
+    case CT_:                                                                                           \
+        if (f16) {                                                                                      \
+            if (deterministic) launch_k64<CT_, true, 1, false>(K64_ARGS);                               \
+            else launch_k64<CT_, true, 1, true>(K64_ARGS);                                              \
+        } else if (vreg == 2) {                                                                         \
+            if (deterministic) launch_k64<CT_, false, 2, false>(K64_ARGS);                              \
+            else launch_k64<CT_, false, 2, true>(K64_ARGS);                                             \
+        } else {                                                                                        \
+            if (deterministic) launch_k64<CT_, false, 1, false>(K64_ARGS);                              \
+            else launch_k64<CT_, false, 1, true>(K64_ARGS);                                             \
+        }                                                                                               \
+        break;
+    switch (Cp / 32) {
+        K64_CASE(1) K64_CASE(2) K64_CASE(3) K64_CASE(4) K64_CASE(5) K64_CASE(6)
+        default: gd_set_error("pam: Cp must be 32..192"); return -1;
+    }
+#undef K64_CASE
+#undef K64_ARGS
+    if (deterministic)
+        gd_pam_dq_reduce_launch(dq_scr, Npad / 256, Npad, nb, dqn, stream);
+    else
+        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn);
+    GD_LAUNCH_CHECK();
+    return 0;
+}

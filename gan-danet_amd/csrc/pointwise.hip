@@ -156,8 +156,13 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
                                                        const float* __restrict__ scale, float scale_imm,
                                                        unsigned short* __restrict__ plain, int Rp, int ldp,
                                                        unsigned short* __restrict__ tr, int Ccp, int ldt, int perm16,
-                                                       int ones_row) {
+                                                       int ones_row, int f16) {
     __shared__ float tile[32][33];
+    // 16-bit output type: bf16 (round to nearest even) or IEEE fp16 (BASELINE config 5)
+    auto cvt = [f16](float v) -> unsigned short {
+        if (f16) return __builtin_bit_cast(unsigned short, (_Float16)v);
+        return gd_f2bf(v);
+    };
     const int b = blockIdx.z;
     const float* sp = s + (long)b * s_bs;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -171,14 +176,14 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
             // perm16: inside every group of 16 columns store [0-3, 8-11, 4-7, 12-15], the order in which a lane half
             // consumes an accumulator-row-ordered k-step -- its fragment becomes ONE 16-byte read
             const int cc = perm16 ? ((c & ~15) | ((c & 3) | ((c & 4) << 1) | ((c & 8) >> 1))) : c;
-            plain[(long)b * Rp * ldp + (long)r * ldp + cc] = gd_f2bf(v);
+            plain[(long)b * Rp * ldp + (long)r * ldp + cc] = cvt(v);
         }
     }
     if (tr) {
         __syncthreads();
         for (int i = ty; i < 32; i += 8) {
             const int c = c0 + i, r = r0 + tx;
-            if (c < Ccp && r < ldt) tr[(long)b * Ccp * ldt + (long)c * ldt + r] = gd_f2bf(tile[tx][i]);
+            if (c < Ccp && r < ldt) tr[(long)b * Ccp * ldt + (long)c * ldt + r] = cvt(tile[tx][i]);
         }
     }
 }
@@ -473,24 +478,30 @@ extern "C" int gd_add_transpose(const float* a, float* out, int B, int n, void* 
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm,
-                            void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16,
-                            int ones_row, void* stream) {
-    GD_CHECK_ARG(s && (plain || transposed) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_bf16: bad arguments");
-    GD_CHECK_ARG(!plain || (Rp_plain >= R && ld_plain >= Cc), "gd_pack_bf16: plain padding smaller than the data");
-    GD_CHECK_ARG(!perm16 || (plain && ld_plain % 16 == 0), "gd_pack_bf16: perm16 needs a plain output with ld % 16 == 0");
-    GD_CHECK_ARG(!transposed || (Ccp_t >= Cc && ld_t >= R), "gd_pack_bf16: transposed padding smaller than the data");
+extern "C" int gd_pack_16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm,
+                          void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16,
+                          int ones_row, int f16, void* stream) {
+    GD_CHECK_ARG(s && (plain || transposed) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_16: bad arguments");
+    GD_CHECK_ARG(!plain || (Rp_plain >= R && ld_plain >= Cc), "gd_pack_16: plain padding smaller than the data");
+    GD_CHECK_ARG(!perm16 || (plain && ld_plain % 16 == 0), "gd_pack_16: perm16 needs a plain output with ld % 16 == 0");
+    GD_CHECK_ARG(!transposed || (Ccp_t >= Cc && ld_t >= R), "gd_pack_16: transposed padding smaller than the data");
     GD_CHECK_ARG(ones_row < 0 || (ones_row >= R && (!plain || ones_row < Rp_plain) && (!transposed || ones_row < ld_t)),
-                 "gd_pack_bf16: ones_row must be a padding row");
+                 "gd_pack_16: ones_row must be a padding row");
     int rows = R, cols = Cc;
     if (plain) { rows = rows > Rp_plain ? rows : Rp_plain; cols = cols > ld_plain ? cols : ld_plain; }
     if (transposed) { rows = rows > ld_t ? rows : ld_t; cols = cols > Ccp_t ? cols : Ccp_t; }
-    GD_CHECK_ARG(gd_cdiv(rows, 32) <= 65535, "gd_pack_bf16: too many rows");
+    GD_CHECK_ARG(gd_cdiv(rows, 32) <= 65535, "gd_pack_16: too many rows");
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
                        scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
-                       ld_t, perm16, ones_row);
+                       ld_t, perm16, ones_row, f16);
     GD_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm,
+                            void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16,
+                            int ones_row, void* stream) {
+    return gd_pack_16(s, s_bs, B, R, Cc, scale_dev, scale_imm, plain, Rp_plain, ld_plain, transposed, Ccp_t, ld_t, perm16,
+                      ones_row, 0, stream);
 }
 extern "C" int gd_augment_d4(const float* src, float* dst, int B, int C, int H, int W, const int* ops, const float* noise,
                              float noise_scale, void* stream) {

@@ -542,20 +542,22 @@ LOG2E = 1.4426950408889634    # gd_pam_flash_* take q pre-scaled by log2(e) (inc
 
 
 def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, scale_imm: float = 1.0, plain_shape=None,
-              t_shape=None, perm16: bool = False, ones_row: int = -1):
-    """s: (B, R, Cc)-like fp32 block (per-image dense).  Returns (plain, transposed) bf16 tensors (or None)."""
+              t_shape=None, perm16: bool = False, ones_row: int = -1, f16: bool = False):
+    """s: (B, R, Cc)-like fp32 block (per-image dense).  Returns (plain, transposed) 16-bit tensors (or None):
+    bf16, or IEEE fp16 with ``f16`` (the fused PAM kernels' fp16 operand mode)."""
     sbs = _bview(s, "pack input")
     B = s.shape[0]
     plain = tr = None
     rp = ldp = ccp = ldt = 0
+    dt = torch.float16 if f16 else torch.bfloat16
     if plain_shape is not None:
         rp, ldp = plain_shape
-        plain = torch.empty(B, rp, ldp, device=s.device, dtype=torch.bfloat16)
+        plain = torch.empty(B, rp, ldp, device=s.device, dtype=dt)
     if t_shape is not None:
         ccp, ldt = t_shape
-        tr = torch.empty(B, ccp, ldt, device=s.device, dtype=torch.bfloat16)
-    L.check(lib().gd_pack_bf16(_ptr(s), sbs, B, R, Cc, _ptr(scale), float(scale_imm), _ptr(plain), rp, ldp, _ptr(tr),
-                               ccp, ldt, int(perm16), int(ones_row), _stream()), "gd_pack_bf16")
+        tr = torch.empty(B, ccp, ldt, device=s.device, dtype=dt)
+    L.check(lib().gd_pack_16(_ptr(s), sbs, B, R, Cc, _ptr(scale), float(scale_imm), _ptr(plain), rp, ldp, _ptr(tr),
+                             ccp, ldt, int(perm16), int(ones_row), int(f16), _stream()), "gd_pack_16")
     return plain, tr
 
 
@@ -620,31 +622,48 @@ def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
     return d_raw, delta
 
 
-def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32, v_ones: bool = False):
+def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32, v_ones: bool = False,
+                  f16: bool = False):
     # algorithmic (unpadded) work: 2 N^2 (r + C) per image
     with _Bracket("pam_flash_fwd", 2.0 * N * N * (r_alg + Cn) * B):
-        L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, int(v_ones), _ptr(gamma),
-                                       _ptr(x), _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse), _stream()),
-                "gd_pam_flash_fwd")
+        L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, int(v_ones), int(f16),
+                                       _ptr(gamma), _ptr(x), _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse),
+                                       _stream()), "gd_pam_flash_fwd")
 
 
-PAM_DQ_FUSED = os.environ.get("GD_PAM_DQ_FUSED", "1") != "0"      # 0: two-kernel backward (A/B reference, no scratch)
-PAM_DQ_PART_CAP = 40 << 30                                         # scratch for the dQ parts: at most 40 GiB per call
+# backward form (gandanet.h GD_PAM_BWD_*): GD_PAM_BWD=0 K64 + fp32 atomics for dQ (default), 1 K64 + bf16 parts
+# (bitwise reproducible), 2 the round-1 K32 kernel with bf16 parts, 3 two kernels without scratch.
+# set_deterministic(True) moves the default from 0 to 1.
+PAM_BWD_FORM = int(os.environ.get("GD_PAM_BWD", "0"))
+PAM_SCRATCH_CAP = 40 << 30                                         # scratch of one call: at most 40 GiB
+DETERMINISTIC = False
 
 
-def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0):
-    part, part_bytes = None, 0
-    if PAM_DQ_FUSED:
-        per_image = int(lib().gd_pam_dq_part_bytes(Npad))
-        nslices = -(-(B * per_image) // PAM_DQ_PART_CAP)              # even slices of the batch that fit the cap
+def set_deterministic(on: bool) -> None:
+    """bitwise-reproducible kernels where a faster order-dependent form exists (PAM dQ: parts instead of atomics)"""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+
+
+def pam_bwd_form() -> int:
+    return L.PAM_BWD_K64_PARTS if (DETERMINISTIC and PAM_BWD_FORM == 0) else PAM_BWD_FORM
+
+
+def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0,
+                  f16: bool = False, form: Optional[int] = None):
+    form = pam_bwd_form() if form is None else form
+    scratch, scratch_bytes = None, 0
+    per_image = int(lib().gd_pam_bwd_scratch_bytes(Npad, form))
+    if per_image:
+        nslices = -(-(B * per_image) // PAM_SCRATCH_CAP)              # even slices of the batch that fit the cap
         images = max(1, -(-B // nslices))
-        part_bytes = per_image * images
-        part = torch.empty(part_bytes, device=dqn.device, dtype=torch.uint8)
+        scratch_bytes = per_image * images
+        scratch = torch.empty(scratch_bytes, device=dqn.device, dtype=torch.uint8)
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
         L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(lse), _ptr(delta), B,
-                                       N, Npad, Cp, _ptr(dqn), _ptr(dkn), _ptr(dv), _ptr(part), part_bytes, _stream()),
-                "gd_pam_flash_bwd")
+                                       N, Npad, Cp, int(f16), int(form), _ptr(dqn), _ptr(dkn), _ptr(dv), _ptr(scratch),
+                                       scratch_bytes, _stream()), "gd_pam_flash_bwd")
 
 
 # =====================================================================================================

@@ -141,7 +141,7 @@ class PerceptualLoss(nn.Module):
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         from .config import config
-        if (config.precision == "bf16" and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
+        if (config.precision != "fp32" and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
                 and x.shape[3] % 8 == 0 and self._nhwc_plan() is not None):
             return _PerceptualNhwcFn.apply(x, y, self)
         x3 = x if x.shape[1] == 3 else ops.repeat_channels(x, 3)

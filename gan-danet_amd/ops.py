@@ -23,7 +23,12 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY
 
 
 def _prec() -> int:
-    return L.PREC_BF16 if config.precision == "bf16" else L.PREC_FP32
+    return L.PREC_FP32 if config.precision == "fp32" else L.PREC_BF16
+
+
+def _pam_f16() -> bool:
+    """fp16 operand mode of the fused PAM kernels (config.precision == "fp16"); all other kernels stay bf16"""
+    return config.precision == "fp16"
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -224,13 +229,14 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
         Np, Cp = _npad(N), _cp(Cn)
         # q goes in pre-scaled by log2 e; a spare padded channel of V carries ones (softmax denominator by MFMA)
         ones = Cp - 1 if Cn < Cp else -1
-        _, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32))
-        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31)
-        vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones)
+        f16 = _pam_f16()
+        _, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32), f16=f16)
+        kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=f16)
+        vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones, f16=f16)
         del q, k, v
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
-        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0, f16=f16)
         return True, (qt, kt, kn, vt, o_attn, lse)
     qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)
     s = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
@@ -256,11 +262,12 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         Np, Cp = _npad(N), _cp(Cn)
         d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
         dgamma_p = K.dot(d_raw, None)
-        _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, t_shape=(Np, Cp))
+        f16 = qt.dtype == torch.float16          # the operand type the forward packed
+        _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, t_shape=(Np, Cp), f16=f16)
         dqn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
-        K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn)
+        K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn, f16=f16)
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
         qt_, kt_, v, p, o_attn = pam_saved

@@ -251,12 +251,14 @@ int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate,
 int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * PAM, fused (flash) form in bf16 with fp32 softmax statistics (generator.py:115-122).
- *   qt     : (B, Npad, 32) bf16, d zero-padded to 32, values PRE-SCALED by log2(e)  (gd_pack_bf16 scale_imm):
+ * PAM, fused (flash) form with 16-bit MFMA operands and fp32 softmax statistics (generator.py:115-122).
+ * f16 = 0: bf16 operands (training default); f16 = 1: IEEE fp16 operands (BASELINE config 5) -- the packs below
+ * must then have been made with gd_pack_16(..., f16 = 1).
+ *   qt     : (B, Npad, 32), d zero-padded to 32, values PRE-SCALED by log2(e)  (gd_pack_bf16 scale_imm):
  *            the kernels work in the log2 domain and feed the softmax shift in as the MFMA accumulator input
- *   kt     : (B, Npad, 32) bf16, unscaled, d zero-padded to 31 and d = 31 set to 1.0 (gd_pack_bf16 ones_row = 31):
+ *   kt     : (B, Npad, 32), unscaled, d zero-padded to 31 and d = 31 set to 1.0 (gd_pack_bf16 ones_row = 31):
  *            the forward feeds its running row maximum through that k-slot (so r <= 31)
- *   v      : (B, Cp, Npad) bf16, Cp = C rounded up to 32   (channel-major, keys perm16-ordered: gd_pack_bf16)
+ *   v      : (B, Cp, Npad), Cp = C rounded up to 32   (channel-major, keys perm16-ordered: gd_pack_bf16)
  *   v_ones : != 0 when channel Cp-1 of v is a row of ones (gd_pack_bf16 ones_row; needs C < Cp): the softmax
  *            denominator then comes out of the O MFMAs instead of one VALU add per score
  *   x, out : (B, C, N) fp32 with batch strides; out = gamma * attn + x
@@ -264,21 +266,29 @@ int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream,
  *   lse    : (B, N) fp32 natural-log log-sum-exp of the unscaled energies.   Npad % 256 == 0.
  * ---------------------------------------------------------------------------------------- */
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
-                     int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
+                     int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
                      float* o_attn, float* lse, void* stream);
-/* backward: bf16 inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care);
- * vt (B,Npad,Cp); dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).
- * outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad) -- gradients w.r.t. the
- * UNSCALED q, k, v.  Npad % 256 == 0.  No atomics in either form: bitwise reproducible.
- *   dq_part != NULL (caller-owned scratch of dq_part_bytes >= gd_pam_dq_part_bytes(Npad), i.e. one image's worth;
- *     more lets more images go per launch): ONE key-parallel kernel computes dK, dV and, from the dS tiles it
- *     already holds, bf16 dQ parts per 128-key block [key block][query][32]; a streaming kernel sums the blocks.
- *   dq_part == NULL: the key-parallel kernel for dK/dV, then a query-parallel kernel that recomputes S and dP for dQ
- *     (1.37x the matrix work, no scratch). */
-size_t gd_pam_dq_part_bytes(int Npad);
+/* backward: 16-bit inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care);
+ * vt (B,Npad,Cp); dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).  All packs
+ * zero padded (gd_pack_bf16 does).  Outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad)
+ * -- gradients w.r.t. the UNSCALED q, k, v.  Npad % 256 == 0.
+ * form (GD_PAM_BWD_*):
+ *   0 K64_ATOMIC  one key-parallel kernel, 4 waves x 64 keys per workgroup (one wave per SIMD, dK^T/dV^T in the
+ *                 accumulation registers), dQ summed across key blocks with fp32 atomics (fastest; not bitwise
+ *                 reproducible in dQ)
+ *   1 K64_PARTS   the same kernel storing dQ as one bf16 part per 256-key block + a streaming sum (reproducible)
+ *   2 K32_PARTS   8 waves x 32 keys per workgroup, bf16 dQ parts (the round-1 kernel; reproducible; bf16 only)
+ *   3 TWO_KERNEL  dK/dV kernel, then a query-parallel kernel that recomputes S and dP for dQ (no scratch; bf16 only)
+ * scratch: caller-owned, >= gd_pam_bwd_scratch_bytes(Npad, form) (= one image's worth; more lets more images go per
+ * launch); may be NULL for form 3. */
+#define GD_PAM_BWD_K64_ATOMIC 0
+#define GD_PAM_BWD_K64_PARTS 1
+#define GD_PAM_BWD_K32_PARTS 2
+#define GD_PAM_BWD_TWO_KERNEL 3
+size_t gd_pam_bwd_scratch_bytes(int Npad, int form);
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
-                     const float* lse, const float* delta, int B, int N, int Npad, int Cp, float* dqn, float* dkn,
-                     float* dv, void* dq_part, size_t dq_part_bytes, void* stream);
+                     const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
+                     float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream);
 
 /* CustomDataset.apply_augmentation (datasets.py:181-208) for a batch of tiles as one gather: per-sample op word
  * ops[b] = hflip | vflip << 1 | quarter_turns << 2 | noise << 4 (flip W, flip H, torch.rot90 k, in that order; H == W
@@ -309,6 +319,10 @@ int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int
 int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm, void* plain,
                  int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, int ones_row,
                  void* stream);
+/* the same with the 16-bit output type selectable: f16 = 0 bf16 (== gd_pack_bf16), f16 = 1 IEEE fp16 */
+int gd_pack_16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm, void* plain,
+               int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, int ones_row, int f16,
+               void* stream);
 
 #ifdef __cplusplus
 }

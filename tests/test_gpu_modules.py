@@ -504,12 +504,15 @@ def test_generator_eval_forward_inference_tiles_vs_oracle(gd, shape):
     assert_close(y16, yo, 5e-2, "eval forward bf16", rell2)
 
 
-def test_pam_flash_backward_two_forms_agree_at_bench_and_max_size(gd):
-    """size-independent check where the oracle cannot go: the fused backward (dQ from the key-parallel kernel, bf16 parts
-    per key block) against the two-kernel form (dQ recomputed by a query-parallel kernel) on the same packed operands,
-    at the bench sequence length (N = 256 * 256, C = 184) and at BASELINE config 5's (N = 512 * 512, C = 64); dK / dV come
-    from the same arithmetic and must be bit-identical, dQ differs by the bf16 rounding of the parts"""
+def test_pam_flash_backward_forms_agree_at_bench_and_max_size(gd):
+    """size-independent check where the oracle cannot go: the four backward forms of gd_pam_flash_bwd on the same packed
+    operands -- K64 with fp32 atomics for dQ (default), K64 with bf16 dQ parts, the round-1 K32 kernel with parts, and
+    the two-kernel form that recomputes S / dP for dQ -- at the bench sequence length (N = 256 * 256, C = 184) and at
+    BASELINE config 5's (N = 512 * 512, C = 64).  dK / dV of the two K32-based forms are the same arithmetic
+    (bit-identical); K64 sums the query tiles in a different order (fp32 round-off); dQ through bf16 parts carries their
+    rounding.  The parts forms must be bitwise reproducible."""
     from gan_danet_amd import kern as K
+    from gan_danet_amd import _lib as L
     for (C, side) in ((184, 256), (64, 512)):
         B, N, r = 1, side * side, max(1, C // 8)
         Np, Cp = (N + 255) // 256 * 256, (C + 31) // 32 * 32
@@ -526,21 +529,26 @@ def test_pam_flash_backward_two_forms_agree_at_bench_and_max_size(gd):
         vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones)
         out, o, lse = torch.empty_like(x), torch.empty_like(x), torch.empty(B, N, device=DEV)
         K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0)
-        # rows of P sum to one: attention output of a constant V is that constant (checked through lse-consistency of
-        # the backward below); here: finite output
         assert torch.isfinite(out).all()
         _, dot_ = K.pack_bf16(do, C, N, scale=gamma, t_shape=(Np, Cp))
         _, delta = K.chan_dot(do, o, gamma)
-        res = {}
-        for fused in (True, False):
-            K.PAM_DQ_FUSED = fused
-            try:
-                dq = torch.empty(B, 32, Np, device=DEV)
-                dk = torch.empty(B, 32, Np, device=DEV)
-                dv = torch.empty(B, Cp, Np, device=DEV)
-                K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dq, dk, dv, r_alg=r, c_alg=C)
-            finally:
-                K.PAM_DQ_FUSED = True
-            res[fused] = (dq[:, :r].clone(), dk[:, :r].clone(), dv[:, :C].clone())
-        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
-        assert_close(res[True][0], res[False][0].cpu(), 1e-2, f"dQ fused vs recomputed, N={N}", rell2)
+
+        def run(form):
+            dq = torch.full((B, 32, Np), float("nan"), device=DEV)
+            dk = torch.full((B, 32, Np), float("nan"), device=DEV)
+            dv = torch.full((B, Cp, Np), float("nan"), device=DEV)
+            K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dq, dk, dv, r_alg=r, c_alg=C, form=form)
+            return dq[:, :r, :N].clone(), dk[:, :r, :N].clone(), dv[:, :C, :N].clone()
+
+        ref = run(L.PAM_BWD_TWO_KERNEL)
+        k32 = run(L.PAM_BWD_K32_PARTS)
+        assert torch.equal(k32[1], ref[1]) and torch.equal(k32[2], ref[2])
+        assert_close(k32[0], ref[0].cpu(), 1e-2, f"dQ K32 parts vs recomputed, N={N}", rell2)
+        for form, name in ((L.PAM_BWD_K64_ATOMIC, "K64 atomic"), (L.PAM_BWD_K64_PARTS, "K64 parts")):
+            got = run(form)
+            assert_close(got[1], ref[1].cpu(), 1e-5, f"dK {name}, N={N}", rell2)
+            assert_close(got[2], ref[2].cpu(), 1e-5, f"dV {name}, N={N}", rell2)
+            assert_close(got[0], ref[0].cpu(), 1e-2 if form == L.PAM_BWD_K64_PARTS else 1e-4, f"dQ {name}, N={N}", rell2)
+            if form == L.PAM_BWD_K64_PARTS:
+                again = run(form)
+                assert all(torch.equal(a, b) for a, b in zip(got, again)), "K64 parts form must be bitwise reproducible"

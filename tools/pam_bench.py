@@ -50,11 +50,37 @@ def timeit(fn, name, flops):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(f"{name:10s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s (algorithmic)", flush=True)
+    print(f"{name:16s} {ms:9.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s (algorithmic)", flush=True)
 
 
 fl = 2.0 * N * N * (r + C) * B
+from gan_danet_amd import _lib as L  # noqa: E402
+
 timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0), "fwd", fl)
 d_raw, delta = K.chan_dot(do, o, gamma)
-timeit(lambda: K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dv, r_alg=r, c_alg=C),
-       "bwd", 2 * fl)
+forms = [int(f) for f in os.environ.get("PAM_BENCH_FORMS", "0,1,2,3").split(",")]
+names = {0: "bwd k64 atomic", 1: "bwd k64 parts", 2: "bwd k32 parts", 3: "bwd 2 kernels"}
+ref = None
+for form in forms:
+    timeit(lambda: K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dv, r_alg=r, c_alg=C, form=form),
+           names[form], 2 * fl)
+    cur = (dqn[:, :r, :N].clone(), dkn[:, :r, :N].clone(), dv[:, :C, :N].clone())
+    if ref is None:
+        ref = cur
+    else:
+        print("    vs first form: " + "  ".join(
+            f"{n} {((a - b).norm() / b.norm()).item():.2e}" for n, a, b in zip(("dq", "dk", "dv"), cur, ref)), flush=True)
+if os.environ.get("PAM_BENCH_F16", "1") != "0":
+    # fp16 operand mode (BASELINE config 5): same inputs packed as IEEE fp16
+    _, qt = K.pack_bf16(q, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32), f16=True)
+    kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=True)
+    vn, vt = K.pack_bf16(v, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones, f16=True)
+    _, dot_ = K.pack_bf16(do, C, N, scale=gamma, t_shape=(Np, Cp), f16=True)
+    timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0, f16=True),
+           "fwd fp16", fl)
+    d_raw, delta = K.chan_dot(do, o, gamma)
+    timeit(lambda: K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dv, r_alg=r, c_alg=C, f16=True,
+                                   form=0), "bwd fp16 k64", 2 * fl)
+    cur = (dqn[:, :r, :N].clone(), dkn[:, :r, :N].clone(), dv[:, :C, :N].clone())
+    print("    fp16 vs bf16 first form: " + "  ".join(
+        f"{n} {((a - b).norm() / b.norm()).item():.2e}" for n, a, b in zip(("dq", "dk", "dv"), cur, ref)), flush=True)
