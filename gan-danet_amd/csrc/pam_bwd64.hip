@@ -18,6 +18,7 @@
 //       !ATOMIC: stored as one bf16 part per key block (deterministic; pam_dq_reduce_kernel sums them).
 // No masks: padded queries carry -1e30 as their -lse (P = 0), padded keys only touch padded outputs (the packs are
 // zero filled).
+#include <stdlib.h>
 #include "pam_common.h"
 #include "../../include/gandanet.h"
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int CT, bool F16, int VREG, bool ATOMIC>
+template <int CT, bool F16, int VREG, bool ATOMIC, int ORDER = 0>
 __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ rc,
@@ -133,6 +134,9 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     constexpr int VLDS = 2 - VREG;                 // key tiles per wave whose V rows live in LDS
     constexpr int V_ELEMS = 4 * VLDS * 32 * DLD;
     constexpr int AOPS = ATOMIC ? 4 : 1;           // VMEM operations of one dQ hand-over per wave
+    // schedule variants (A/B switches, see the loop): bit 0 DQ_FIRST, bit 1 HANDOVER_MID, bit 2 DMA_LATE
+    constexpr bool DQ_FIRST = (ORDER & 1) != 0, HANDOVER_MID = (ORDER & 2) != 0, DMA_LATE = (ORDER & 4) != 0;
+    static_assert(!HANDOVER_MID || DQ_FIRST, "the mid-iteration hand-over follows the early dQ steps");
     static_assert(DCH % 64 == 0 && (OFF_X % 8) == 0 && (OFF_XQ % 8) == 0 && (OFF_V % 8) == 0, "LDS carve");
     static_assert((OFF_V + V_ELEMS) * 2 <= 163840, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned short lds[OFF_V + (V_ELEMS ? V_ELEMS : 8)];   // the ONLY LDS object
@@ -244,19 +248,20 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     const unsigned short* v_rows = Vw + r * DLD + 8 * h;
     float* xq_base = reinterpret_cast<float*>(lds + OFF_XQ);
 
-    // hand the previous tile's dQ over: sum the four waves' fp32 parts, then atomics / one bf16 part store
+    // hand the previous tile's dQ over: sum the four waves' fp32 parts (all LDS reads first: ONE round trip), then
+    // atomics / one bf16 part store
     auto dq_handover = [&](int buf, int tq) {
         const float* xr = xq_base + buf * XQ_BUF;
         if constexpr (ATOMIC) {
             float* acc = reinterpret_cast<float*>(dq_out) + (nb + (long)tq * 32) * 32;
+            float v[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = 8 * wave + 2 * k + h;
-                float v = 0.f;
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += xr[w * 32 * QXLD + i * QXLD + r];
-                atomicAdd(acc + i * 32 + r, v);      // one wave-instruction = two adjacent 128-byte rows
-            }
+                for (int w = 0; w < 4; ++w) v[k][w] = xr[w * 32 * QXLD + (8 * wave + 2 * k + h) * QXLD + r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)      // one wave-instruction = two adjacent 128-byte rows
+                atomicAdd(acc + (8 * wave + 2 * k + h) * 32 + r, (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]));
         } else {
             unsigned short* part = reinterpret_cast<unsigned short*>(dq_out) + (((long)b * (Npad / 256) + kb) * Npad + (long)tq * 32) * 32;
             const int i = 8 * wave + (lane >> 3), d4 = (lane & 7) * 4;
@@ -282,9 +287,13 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
         __builtin_amdgcn_s_barrier();
         const int slot = it % NSLOT;
-        dma_tile(tpf, (it + 2) % NSLOT);     // slot of tile it-1: every wave is past its reads (it is past this barrier)
-        tpf = next_tile(tpf);
-        dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
+        // VMEM order per iteration (the vmcnt count above relies on it): DMA of tile it+2 into the slot of tile it-1
+        // (every wave is past its reads of it: it is past this barrier), THEN the dQ hand-over of tile it-1
+        if constexpr (!DMA_LATE) {
+            dma_tile(tpf, (it + 2) % NSLOT);
+            tpf = next_tile(tpf);
+        }
+        if constexpr (!HANDOVER_MID) dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
 
         // every LDS address below = (ring slot base) + (per-lane offset fixed for the whole sweep) + (compile-time
         // immediate): the XOR swizzle of the dO image only touches the low two chunk bits, so it folds into the
@@ -318,6 +327,10 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(q_rows + s * 16);
             sacc[0] = mfma16<F16>(qa, kfB[0][s], sacc[0]);
             sacc[1] = mfma16<F16>(qa, kfB[1][s], sacc[1]);
+        }
+        if constexpr (DMA_LATE) {
+            dma_tile(tpf, (it + 2) % NSLOT);
+            tpf = next_tile(tpf);
         }
         // dP = dO V^T - delta
 #pragma unroll
@@ -354,54 +367,66 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * s + 8) = hi;
             }
         }
-        // dV^T += dO^T P, dK^T += Q^T dS, dQ^T part: all A/B fragments below come from transpose reads (element j of
-        // lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)), issued one batch (4 reads = both k-steps of one tile)
-        // ahead of the MFMAs that consume them
+        // dV^T += dO^T P (CT steps), dK^T += Q^T dS (1 step), dQ^T part (2 steps): every A/B fragment below comes from
+        // a transpose read (element j of lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)), issued one step (4 reads =
+        // both k-steps of one tile) ahead of the MFMAs that consume it.  Step ids: 0..CT-1 dV^T channel tile,
+        // CT dK^T, CT+1 / CT+2 dQ^T over the wave's key tile 0 / 1.
         const unsigned int a_dlo = lds_addr(do_tr_lo), a_dhi = lds_addr(do_tr_hi);
         const unsigned int a_q = lds_addr(q_tr), a_x = lds_addr(x_tr);
-        TrFrag2 fb[CT + 3];     // CT dO^T batches, Q^T, X(key tile 0), X(key tile 1)
-        fb[0] = tr_issue2<0, 16 * DOLD * 2>(a_dlo, a_dhi);
-        static_for<0, CT>([&](auto ic) {
-            constexpr int ct = decltype(ic)::value;
-            if constexpr (ct + 1 < CT) fb[ct + 1] = tr_issue2<(ct + 1) * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
-            else fb[CT] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
-            tr_wait<4>(fb[ct]);
-            const bf16x8_t a0 = tr_frag(fb[ct].lo0, fb[ct].hi0), a1 = tr_frag(fb[ct].lo1, fb[ct].hi1);
-            dvacc[0][ct] = mfma16<F16>(a0, pf[0][0], dvacc[0][ct]);
-            dvacc[1][ct] = mfma16<F16>(a0, pf[1][0], dvacc[1][ct]);
-            dvacc[0][ct] = mfma16<F16>(a1, pf[0][1], dvacc[0][ct]);
-            dvacc[1][ct] = mfma16<F16>(a1, pf[1][1], dvacc[1][ct]);
-        });
-        {   // dK^T += Q^T dS
-            fb[CT + 1] = tr_issue2<0, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
-            tr_wait<4>(fb[CT]);
-            const bf16x8_t a0 = tr_frag(fb[CT].lo0, fb[CT].hi0), a1 = tr_frag(fb[CT].lo1, fb[CT].hi1);
-            dkacc[0] = mfma16<F16>(a0, dsf[0][0], dkacc[0]);
-            dkacc[1] = mfma16<F16>(a0, dsf[1][0], dkacc[1]);
-            dkacc[0] = mfma16<F16>(a1, dsf[0][1], dkacc[0]);
-            dkacc[1] = mfma16<F16>(a1, dsf[1][1], dkacc[1]);
-        }
-        // dQ^T part of this wave's 64 keys: transpose read = the B operand (lane = query, k = key)
+        TrFrag2 fb[CT + 3];
         f32x16_t dqp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqp[e] = 0.f;
-        {
-            fb[CT + 2] = tr_issue2<32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
-            tr_wait<4>(fb[CT + 1]);
-            dqp = mfma16<F16>(knA[0][0], tr_frag(fb[CT + 1].lo0, fb[CT + 1].hi0), dqp);
-            dqp = mfma16<F16>(knA[0][1], tr_frag(fb[CT + 1].lo1, fb[CT + 1].hi1), dqp);
-            tr_wait<0>(fb[CT + 2]);
-            dqp = mfma16<F16>(knA[1][0], tr_frag(fb[CT + 2].lo0, fb[CT + 2].hi0), dqp);
-            dqp = mfma16<F16>(knA[1][1], tr_frag(fb[CT + 2].lo1, fb[CT + 2].hi1), dqp);
-        }
-        {
+        auto issue = [&](auto idc) {
+            constexpr int id = decltype(idc)::value;
+            if constexpr (id < CT) fb[id] = tr_issue2<id * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
+            else if constexpr (id == CT) fb[id] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
+            else fb[id] = tr_issue2<(id - CT - 1) * 32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
+        };
+        auto compute = [&](auto idc) {
+            constexpr int id = decltype(idc)::value;
+            const bf16x8_t a0 = tr_frag(fb[id].lo0, fb[id].hi0), a1 = tr_frag(fb[id].lo1, fb[id].hi1);
+            if constexpr (id < CT) {
+                dvacc[0][id] = mfma16<F16>(a0, pf[0][0], dvacc[0][id]);
+                dvacc[1][id] = mfma16<F16>(a0, pf[1][0], dvacc[1][id]);
+                dvacc[0][id] = mfma16<F16>(a1, pf[0][1], dvacc[0][id]);
+                dvacc[1][id] = mfma16<F16>(a1, pf[1][1], dvacc[1][id]);
+            } else if constexpr (id == CT) {
+                dkacc[0] = mfma16<F16>(a0, dsf[0][0], dkacc[0]);
+                dkacc[1] = mfma16<F16>(a0, dsf[1][0], dkacc[1]);
+                dkacc[0] = mfma16<F16>(a1, dsf[0][1], dkacc[0]);
+                dkacc[1] = mfma16<F16>(a1, dsf[1][1], dkacc[1]);
+            } else {
+                // transpose read of X = the B operand (lane = query, k = key)
+                dqp = mfma16<F16>(knA[id - CT - 1][0], a0, dqp);
+                dqp = mfma16<F16>(knA[id - CT - 1][1], a1, dqp);
+            }
+        };
+        auto xq_write = [&]() {
             float* xw = xq_base + (it & 1) * XQ_BUF + wave * 32 * QXLD + r * QXLD + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4_t v = {dqp[4 * g], dqp[4 * g + 1], dqp[4 * g + 2], dqp[4 * g + 3]};
                 *reinterpret_cast<f32x4_t*>(xw + 8 * g) = v;
             }
-        }
+        };
+        constexpr int NSTEP = CT + 3;
+        // DQ_FIRST: the dQ^T steps (and the exchange-buffer write) go in front of the dV^T / dK^T steps, so that the
+        // iteration ends on independent MFMAs instead of a dependent chain + an LDS write in front of the barrier
+        auto step_id = [](int i) constexpr { return DQ_FIRST ? (i < 2 ? CT + 1 + i : i - 2) : i; };
+        issue(IC<step_id(0)>{});
+        static_for<0, NSTEP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int id = step_id(i);
+            if constexpr (i + 1 < NSTEP) issue(IC<step_id(i + 1)>{});
+            if constexpr (i + 1 < NSTEP) tr_wait<4>(fb[id]);
+            else tr_wait<0>(fb[id]);
+            compute(IC<id>{});
+            if constexpr (id == CT + 2) {       // dQ^T part complete
+                xq_write();
+                if constexpr (HANDOVER_MID) dq_handover((it + 1) & 1, tprev);
+            }
+        });
         tprev = tcur;
         tcur = next_tile(tcur);
     }
@@ -444,12 +469,20 @@ void launch_k64(dim3 grid, hipStream_t s, const unsigned short* q, const unsigne
 
 extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int nb, float* dqn, void* stream);   // pam.hip
 
+// bench tooling: schedule variant of the K64 kernel (0 = production) and V-in-registers count (0 = default)
+static int g_k64_order = 0, g_k64_vreg = 0;
+extern "C" void gd_pam_k64_variant(int order, int vreg) {
+    g_k64_order = order;
+    g_k64_vreg = vreg;
+}
+
 // one batch slice through the 64-keys-per-wave backward; scratch holds `images` images' worth
 extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                   const float* lse, const float* delta, int nb, int N, int Npad, int Cp, int f16,
                                   int vreg, int deterministic, float* dqn, float* dkn, float* dv, void* scratch,
                                   void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (g_k64_vreg) vreg = g_k64_vreg;
     float* rc = reinterpret_cast<float*>(scratch);
     char* dq_scr = reinterpret_cast<char*>(scratch) + (size_t)nb * Npad * 2 * sizeof(float);
     hipLaunchKernelGGL(pam_rowconst_kernel, dim3(Npad / 256, nb), dim3(256), 0, s, lse, delta, N, Npad, rc);
@@ -466,8 +499,8 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
 #define K64_CASE(CT_)                                                                                   \
     case CT_:                                                                                           \
         if (f16) {                                                                                      \
-            if (deterministic) launch_k64<CT_, true, 1, false>(K64_ARGS);                               \
-            else launch_k64<CT_, true, 1, true>(K64_ARGS);                                              \
+            if (deterministic) launch_k64<CT_, true, 2, false>(K64_ARGS);                               \
+            else launch_k64<CT_, true, 2, true>(K64_ARGS);                                              \
         } else if (vreg == 2) {                                                                         \
             if (deterministic) launch_k64<CT_, false, 2, false>(K64_ARGS);                              \
             else launch_k64<CT_, false, 2, true>(K64_ARGS);                                             \
@@ -476,6 +509,21 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
             else launch_k64<CT_, false, 1, true>(K64_ARGS);                                             \
         }                                                                                               \
         break;
+    if (g_k64_order && Cp == 192 && !f16 && !deterministic) {     // schedule A/B variants (bench tooling only)
+#define K64_ORD(O_)                                                                                          \
+    case O_:                                                                                                 \
+        if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
+        else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
+        break;
+        switch (g_k64_order) {
+            K64_ORD(1) K64_ORD(3) K64_ORD(4) K64_ORD(5)
+            default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
+        }
+#undef K64_ORD
+        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn);
+        GD_LAUNCH_CHECK();
+        return 0;
+    }
     switch (Cp / 32) {
         K64_CASE(1) K64_CASE(2) K64_CASE(3) K64_CASE(4) K64_CASE(5) K64_CASE(6)
         default: gd_set_error("pam: Cp must be 32..192"); return -1;

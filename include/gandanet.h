@@ -286,6 +286,9 @@ int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N
 #define GD_PAM_BWD_K32_PARTS 2
 #define GD_PAM_BWD_TWO_KERNEL 3
 size_t gd_pam_bwd_scratch_bytes(int Npad, int form);
+/* tuning hook (bench tooling; process-global, not thread safe): schedule variant of the K64 kernel (0 = production)
+ * and the number of a wave's two key tiles whose V rows stay in registers (1 or 2; 0 = default). */
+void gd_pam_k64_variant(int order, int vreg);
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
                      float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream);
