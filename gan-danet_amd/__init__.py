@@ -10,6 +10,7 @@ repo-root ``gan_danet_amd.py`` registers the package under that name -- or throu
 import paths ``from models import ...`` / ``from model import ...``.
 """
 from .config import config, precision, set_precision
+from .kern import set_deterministic
 from .discriminator import SRGAND, Discriminator1
 from .generator import (CAMModule, CBAMBlock, DANetAttention, DenseBlock, DenseLayer, FlexibleUpsamplingModule,
                         OriginalRelationshipLearner, PAMModule, SqueezeExcitation, TransitionLayer)

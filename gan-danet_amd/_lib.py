@@ -53,6 +53,8 @@ _i, _l, _f, _p, _sz = C.c_int, C.c_long, C.c_float, c_fp, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/gandanet.h
 SIGNATURES = {
     "gd_version": (_i, []),
+    "gd_set_deterministic": (None, [_i]),
+    "gd_get_deterministic": (_i, []),
     "gd_last_error": (_i, [C.c_char_p, _i]),
     "gd_sizeof_conv_desc": (_i, []),
     "gd_sizeof_gemm_nt_desc": (_i, []),
@@ -87,10 +89,15 @@ SIGNATURES = {
     "gd_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "gd_add_transpose": (_i, [_p, _p, _i, _i, _p]),
     "gd_bce_logits": (_i, [_p, _l, _f, _p, _p, _p, _p]),
+    "gd_bce_logits_target": (_i, [_p, _p, _l, _p, _p, _p, _p, _p]),
+    "gd_leaky_fwd": (_i, [_p, _p, _l, _f, _p]),
+    "gd_leaky_bwd": (_i, [_p, _p, _p, _l, _f, _p]),
     "gd_mse": (_i, [_p, _p, _l, _p, _p, _p, _p]),
     "gd_l1": (_i, [_p, _p, _l, _p, _p, _p, _p]),
     "gd_tv": (_i, [_p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "gd_ssim": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "gd_ssim_samples": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "gd_ssim_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gd_adamw": (_i, [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f, _p]),
     "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p]),
     "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),

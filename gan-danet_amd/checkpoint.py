@@ -5,7 +5,10 @@
   module and vice versa.
 * ``EarlyStopping``: the patience / min_delta rule of L271-283.
 * ``save_training_state`` / ``load_training_state``: what the reference does NOT keep -- discriminator, both AdamW
-  states, the LR schedulers and the epoch counter -- so that a run resumes bit-for-bit.
+  states, the LR schedulers and the epoch counter -- so that a run resumes to fp32 round-off (bit-for-bit under
+  ``gd.set_deterministic(True)``: the default split-K / weight-gradient / PAM dQ sums use fp32 atomics, whose order
+  varies from launch to launch).
+* under data parallelism only rank 0 writes files (replicas are identical); every rank reads.
 * ensemble (deep_ensemble.ipynb c0:270-337): members are independent replicas with seeds 42 + i; on an N-GPU node
   member i trains on rank i % N with NO gradient exchange (``GanTrainer(reduce_gradients=False)``), and the
   prediction mean / spread of ``compute_uncertainty`` (c0:410-448) is a reduction over the member axis.
@@ -22,9 +25,19 @@ import numpy as np
 import torch
 from torch import nn
 
+from .parallel import rank as _rank
 
-def save_generator(G: nn.Module, path: str = "best_model.pth") -> None:
-    torch.save(G.state_dict(), path)
+
+def _atomic_save(obj, path: str) -> None:
+    tmp = f"{path}.tmp{os.getpid()}"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)          # a crash mid-write never leaves a truncated file under the final name
+
+
+def save_generator(G: nn.Module, path: str = "best_model.pth", all_ranks: bool = False) -> None:
+    """rank 0 only under data parallelism (replicas are identical; ``all_ranks`` for independent ensemble members)"""
+    if all_ranks or _rank() == 0:
+        _atomic_save(G.state_dict(), path)
 
 
 def load_generator(G: nn.Module, path: str = "best_model.pth", device=None) -> nn.Module:
@@ -33,10 +46,13 @@ def load_generator(G: nn.Module, path: str = "best_model.pth", device=None) -> n
 
 
 class EarlyStopping:
-    """L259-283: keep the best generator, stop after ``patience`` epochs without an improvement > ``min_delta``."""
+    """L208-291: keep the best generator, stop after ``patience`` (20 in the notebook, L208) epochs without an
+    improvement > ``min_delta``; ``finish`` reloads the best weights at a normal end of training too (L290, L307).
+    ``all_ranks``: every process writes (independent ensemble members with their own paths)."""
 
-    def __init__(self, patience: int = 10, min_delta: float = 0.0, path: str = "best_model.pth") -> None:
-        self.patience, self.min_delta, self.path = patience, min_delta, path
+    def __init__(self, patience: int = 20, min_delta: float = 0.0, path: str = "best_model.pth",
+                 all_ranks: bool = False) -> None:
+        self.patience, self.min_delta, self.path, self.all_ranks = patience, min_delta, path, all_ranks
         self.best_loss = float("inf")
         self.trigger_times = 0
 
@@ -45,13 +61,23 @@ class EarlyStopping:
         if avg_epoch_loss_g < self.best_loss - self.min_delta:
             self.best_loss = avg_epoch_loss_g
             self.trigger_times = 0
-            save_generator(G, self.path)
+            save_generator(G, self.path, self.all_ranks)
             return False
         self.trigger_times += 1
         if self.trigger_times >= self.patience:
-            load_generator(G, self.path, next(G.parameters()).device)
+            self.finish(G)
             return True
         return False
+
+    def finish(self, G: nn.Module) -> nn.Module:
+        """load the best generator back (end of training, L290 / L307); under data parallelism the other ranks wait
+        for rank 0's file"""
+        import torch.distributed as dist
+        if not self.all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+        if os.path.exists(self.path):
+            load_generator(G, self.path, next(G.parameters()).device)
+        return G
 
 
 def save_training_state(path: str, trainer, epoch: int, schedulers: Sequence = (), extra: Optional[Dict] = None) -> None:
@@ -66,9 +92,8 @@ def save_training_state(path: str, trainer, epoch: int, schedulers: Sequence = (
     }
     if getattr(trainer, "input_attention", None) is not None:
         state["input_attention"] = trainer.input_attention.state_dict()
-    tmp = path + ".tmp"
-    torch.save(state, tmp)
-    os.replace(tmp, path)          # a crash mid-write never leaves a truncated checkpoint under the final name
+    if _rank() == 0 or not getattr(trainer, "_reduce", True):      # replicas are identical: one writer
+        _atomic_save(state, path)
 
 
 def load_training_state(path: str, trainer, schedulers: Sequence = ()) -> Dict:

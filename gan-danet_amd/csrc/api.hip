@@ -27,3 +27,12 @@ extern "C" int gd_version(void) { return GD_VERSION; }
 // struct sizes, so a binding can verify its mirror of the descriptors
 extern "C" int gd_sizeof_conv_desc(void) { return (int)sizeof(gd_conv_desc); }
 extern "C" int gd_sizeof_gemm_nt_desc(void) { return (int)sizeof(gd_gemm_nt_desc); }
+
+// Deterministic mode: kernels that combine partial sums with fp32 atomics (split-K NT GEMM, 3x3
+// weight gradient) run unsplit -- one adder per output element, bitwise reproducible, slower.  The PAM backward's dQ
+// form is chosen by its caller (gd_pam_flash_bwd form 1).  Process-global.
+namespace {
+int g_deterministic = 0;
+}
+extern "C" void gd_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }
+extern "C" int gd_get_deterministic(void) { return g_deterministic; }

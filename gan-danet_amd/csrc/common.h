@@ -70,6 +70,7 @@ __device__ __forceinline__ float gd_block_max(float v, float* red) {
 
 // ---- error plumbing for the C ABI -------------------------------------------------------------
 extern "C" void gd_set_error(const char* msg);
+extern "C" int gd_get_deterministic(void);   // api.hip: 1 = no order-dependent (atomic) reductions
 #define GD_CHECK_ARG(cond, msg)          \
     do {                                 \
         if (!(cond)) {                   \

@@ -695,7 +695,7 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16
     const int bm = cs ? 32 : 32 * best_nw;
     const int mblocks = (Cout + bm - 1) / bm;
     long splits = 1024 / ((long)mblocks * groups);
-    if (splits < 1) splits = 1;
+    if (splits < 1 || gd_get_deterministic()) splits = 1;    // deterministic mode: one adder per dW element
     if (splits > ntiles) splits = ntiles;
     if (splits > 65535) splits = 65535;
     a.tiles_per_split = (int)((ntiles + splits - 1) / splits);

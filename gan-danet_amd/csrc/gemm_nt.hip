@@ -317,6 +317,7 @@ extern "C" int gd_gemm_nt(const gd_gemm_nt_desc* dp, void* stream) {
         if (splits > ktiles / 8) splits = ktiles / 8 > 0 ? ktiles / 8 : 1;
     }
     if (splits > ktiles) splits = ktiles;
+    if (gd_get_deterministic()) splits = 1;                  // deterministic mode: no atomic combine of k-splits
     if ((long)d.B * splits > 65535) splits = (int)(65535 / d.B);
     hipStream_t s = (hipStream_t)stream;
     if (bm == 32) return launch<32>(d, ktiles, splits, s);

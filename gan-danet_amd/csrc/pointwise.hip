@@ -297,6 +297,33 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, l
     s = gd_block_sum(s, red);
     if (threadIdx.x == 0) ws[blockIdx.x] = s;
 }
+// BCE with logits against a per-element target tensor (torch.nn.BCEWithLogitsLoss, mean); dt: gradient w.r.t. target
+__global__ __launch_bounds__(256) void bce_target_kernel(const float* __restrict__ z, const float* __restrict__ t, long n,
+                                                        float inv_n, float* __restrict__ dz, float* __restrict__ dt,
+                                                        float* __restrict__ ws) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = z[i], y = t[i];
+        s += fmaxf(v, 0.f) - v * y + log1pf(expf(-fabsf(v)));
+        if (dz) dz[i] = (1.f / (1.f + expf(-v)) - y) * inv_n;
+        if (dt) dt[i] = -v * inv_n;
+    }
+    s = gd_block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+// LeakyReLU with an arbitrary slope (the fused epilogues know 0.2 only: discriminator.py:62-77 uses nothing else)
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = v >= 0.f ? v : slope * v;
+    }
+}
+__global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n,
+                                 float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = x[i] >= 0.f ? dy[i] : slope * dy[i];     // on the INPUT's sign: valid for every slope, 0 and negative too
+}
 template <bool L1>
 __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                        float inv_n, float* __restrict__ da, float* __restrict__ ws) {
@@ -381,6 +408,88 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, 
     }
     s = gd_block_sum(s, red);
     if (threadIdx.x == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// SSIM backward (losses.py:118-136 under autograd), two passes over the image.
+// With m1 = G*a, m2 = G*b, e11 = G*a^2, e22 = G*b^2, e12 = G*ab (G = the zero-padded Gaussian window, symmetric, so the
+// adjoint of each filtering is the same filtering) and A1 = 2 m1 m2 + c1, A2 = 2 (e12 - m1 m2) + c2,
+// B1 = m1^2 + m2^2 + c1, B2 = e11 - m1^2 + e22 - m2^2 + c2, ssim = A1 A2 / (B1 B2):
+//   d/dm1 = 2 m2 (A2 - A1) / (B1 B2) - 2 m1 ssim (1/B1 - 1/B2)      d/dm2: m1 <-> m2
+//   d/de12 = 2 A1 / (B1 B2)                                          d/de11 = d/de22 = -ssim / B2
+// pass 1 writes the four coefficient planes (times the upstream factor of the sample), pass 2 filters them:
+//   da = G*P1 + 2 a (G*P3) + b (G*P4),   db = G*P2 + 2 b (G*P3) + a (G*P4)
+__global__ __launch_bounds__(256) void ssim_bwd_coef_kernel(const float* __restrict__ a, const float* __restrict__ b, int C,
+                                                           int H, int W, SsimWin win, const float* __restrict__ gscale,
+                                                           float* __restrict__ coef) {
+    const long plane = blockIdx.y, hw = (long)H * W;
+    const float* pa = a + plane * hw;
+    const float* pb = b + plane * hw;
+    const float g = gscale[plane / C];
+    float* pc = coef + plane * 4 * hw;
+    const int half = win.n / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const int yy = (int)(i / W), xx = (int)(i - (long)yy * W);
+        float m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+        for (int dy = 0; dy < win.n; ++dy) {
+            const int y2 = yy + dy - half;
+            if (y2 < 0 || y2 >= H) continue;
+            for (int dx = 0; dx < win.n; ++dx) {
+                const int x2 = xx + dx - half;
+                if (x2 < 0 || x2 >= W) continue;
+                const float w = win.g[dy] * win.g[dx];
+                const float u = pa[(long)y2 * W + x2], v = pb[(long)y2 * W + x2];
+                m1 = fmaf(w, u, m1); m2 = fmaf(w, v, m2);
+                s11 = fmaf(w, u * u, s11); s22 = fmaf(w, v * v, s22); s12 = fmaf(w, u * v, s12);
+            }
+        }
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+        const float A1 = 2.f * m12 + c1, A2 = 2.f * (s12 - m12) + c2;
+        const float B1 = m1s + m2s + c1, B2 = (s11 - m1s) + (s22 - m2s) + c2;
+        const float inv = 1.f / (B1 * B2), ss = A1 * A2 * inv;
+        const float t = 2.f * (A2 - A1) * inv, u2 = 2.f * ss * (1.f / B1 - 1.f / B2);
+        pc[i] = g * (m2 * t - m1 * u2);
+        pc[hw + i] = g * (m1 * t - m2 * u2);
+        pc[2 * hw + i] = g * (-ss / B2);
+        pc[3 * hw + i] = g * (2.f * A1 * inv);
+    }
+}
+__global__ __launch_bounds__(256) void ssim_bwd_filter_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int H, int W, SsimWin win, const float* __restrict__ coef,
+                                                             float* __restrict__ da, float* __restrict__ db) {
+    const long plane = blockIdx.y, hw = (long)H * W;
+    const float* pc = coef + plane * 4 * hw;
+    const int half = win.n / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const int yy = (int)(i / W), xx = (int)(i - (long)yy * W);
+        float f1 = 0, f2 = 0, f3 = 0, f4 = 0;
+        for (int dy = 0; dy < win.n; ++dy) {
+            const int y2 = yy + dy - half;
+            if (y2 < 0 || y2 >= H) continue;
+            for (int dx = 0; dx < win.n; ++dx) {
+                const int x2 = xx + dx - half;
+                if (x2 < 0 || x2 >= W) continue;
+                const float w = win.g[dy] * win.g[dx];
+                const long j = (long)y2 * W + x2;
+                f1 = fmaf(w, pc[j], f1); f2 = fmaf(w, pc[hw + j], f2);
+                f3 = fmaf(w, pc[2 * hw + j], f3); f4 = fmaf(w, pc[3 * hw + j], f4);
+            }
+        }
+        const float u = a[plane * hw + i], v = b[plane * hw + i];
+        if (da) da[plane * hw + i] = f1 + 2.f * u * f3 + v * f4;
+        if (db) db[plane * hw + i] = f2 + 2.f * v * f3 + u * f4;
+    }
+}
+// out[s] = scale * sum of row s of ws (rows x n partial sums)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws, int n, float scale,
+                                                         float* __restrict__ out) {
+    __shared__ double redd[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += ws[(long)blockIdx.x * n + i];
+    acc = gd_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)((redd[0] + redd[1] + redd[2] + redd[3]) * (double)scale);
 }
 
 // ---- AdamW -----------------------------------------------------------------------------------------------------
@@ -556,6 +665,27 @@ extern "C" int gd_bce_logits(const float* z, long n, float label, float* out, fl
     GD_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int gd_bce_logits_target(const float* z, const float* t, long n, float* out, float* dz, float* dt, float* ws,
+                                    void* stream) {
+    GD_CHECK_ARG(z && t && out && ws && n > 0, "gd_bce_logits_target: bad arguments");
+    const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
+    hipLaunchKernelGGL(bce_target_kernel, dim3(g), dim3(256), 0, GD_S, z, t, n, 1.f / (float)n, dz, dt, ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, g, 1.f / (float)n, out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_leaky_fwd(const float* x, float* y, long n, float slope, void* stream) {
+    GD_CHECK_ARG(x && y && n > 0, "gd_leaky_fwd: bad arguments");
+    hipLaunchKernelGGL(leaky_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, x, y, n, slope);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_leaky_bwd(const float* x, const float* dy, float* dx, long n, float slope, void* stream) {
+    GD_CHECK_ARG(x && dy && dx && n > 0, "gd_leaky_bwd: bad arguments");
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, GD_S, x, dy, dx, n, slope);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gd_mse(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream) {
     GD_CHECK_ARG(a && b && out && ws && n > 0, "gd_mse: bad arguments");
     const int g = grid_for(n) > RED_BLOCKS ? RED_BLOCKS : grid_for(n);
@@ -585,12 +715,9 @@ extern "C" int gd_tv(const float* x, int B, int C, int H, int W, float weight, f
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_ssim(const float* a, const float* b, int BC, int H, int W, int window, float* out, float* ws,
-                       void* stream) {
-    GD_CHECK_ARG(a && b && out && ws && BC > 0 && H > 0 && W > 0, "gd_ssim: bad arguments");
-    GD_CHECK_ARG(window > 0 && window <= 15 && (window & 1), "gd_ssim: window must be odd and <= 15");
-    SsimWin win;
-    win.n = window;
+static int ssim_window(int window, SsimWin* win) {
+    if (!(window > 0 && window <= 15 && (window & 1))) return -1;
+    win->n = window;
     // SSIM._gaussian (losses.py:98-101): fp32 exp, normalised by the fp32 sum
     float tmp[16], sum = 0.f;
     for (int i = 0; i < window; ++i) {
@@ -598,14 +725,51 @@ extern "C" int gd_ssim(const float* a, const float* b, int BC, int H, int W, int
         tmp[i] = expf(-(d * d) / (2.f * 1.5f * 1.5f));
         sum += tmp[i];
     }
-    for (int i = 0; i < 16; ++i) win.g[i] = i < window ? tmp[i] / sum : 0.f;
+    for (int i = 0; i < 16; ++i) win->g[i] = i < window ? tmp[i] / sum : 0.f;
+    return 0;
+}
+static int ssim_gx(int H, int W, int BC) {
     int gx = (int)(((long)H * W + 255) / 256);
     if (gx > 64) gx = 64;
     while ((long)gx * BC > 2048 && gx > 1) gx >>= 1;
+    return gx;
+}
+extern "C" int gd_ssim(const float* a, const float* b, int BC, int H, int W, int window, float* out, float* ws,
+                       void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && BC > 0 && H > 0 && W > 0, "gd_ssim: bad arguments");
+    SsimWin win;
+    GD_CHECK_ARG(ssim_window(window, &win) == 0, "gd_ssim: window must be odd and <= 15");
+    const int gx = ssim_gx(H, W, BC);
     GD_CHECK_ARG((long)gx * BC <= 2048 && BC <= 65535, "gd_ssim: too many planes for the workspace");
     hipLaunchKernelGGL(ssim_kernel, dim3(gx, BC), dim3(256), 0, GD_S, a, b, H, W, win, ws);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, GD_S, ws, gx * BC, 1.f / ((float)BC * (float)H * (float)W),
                        out, 0);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_ssim_samples(const float* a, const float* b, int B, int C, int H, int W, int window, float* out,
+                               float* ws, void* stream) {
+    GD_CHECK_ARG(a && b && out && ws && B > 0 && C > 0 && H > 0 && W > 0, "gd_ssim_samples: bad arguments");
+    SsimWin win;
+    GD_CHECK_ARG(ssim_window(window, &win) == 0, "gd_ssim_samples: window must be odd and <= 15");
+    const int BC = B * C, gx = ssim_gx(H, W, BC);
+    GD_CHECK_ARG((long)gx * BC <= 2048 && BC <= 65535, "gd_ssim_samples: too many planes for the workspace");
+    hipLaunchKernelGGL(ssim_kernel, dim3(gx, BC), dim3(256), 0, GD_S, a, b, H, W, win, ws);
+    // ws is [plane][gx]: a sample's C planes are consecutive
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(B), dim3(256), 0, GD_S, ws, gx * C, 1.f / ((float)C * (float)H * (float)W), out);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_ssim_bwd(const float* a, const float* b, const float* gscale, int B, int C, int H, int W, int window,
+                           float* coef_ws, float* da, float* db, void* stream) {
+    GD_CHECK_ARG(a && b && gscale && coef_ws && (da || db) && B > 0 && C > 0 && H > 0 && W > 0, "gd_ssim_bwd: bad arguments");
+    SsimWin win;
+    GD_CHECK_ARG(ssim_window(window, &win) == 0, "gd_ssim_bwd: window must be odd and <= 15");
+    GD_CHECK_ARG((long)B * C <= 65535, "gd_ssim_bwd: too many planes");
+    int gx = (int)(((long)H * W + 255) / 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(ssim_bwd_coef_kernel, dim3(gx, B * C), dim3(256), 0, GD_S, a, b, C, H, W, win, gscale, coef_ws);
+    hipLaunchKernelGGL(ssim_bwd_filter_kernel, dim3(gx, B * C), dim3(256), 0, GD_S, a, b, H, W, win, coef_ws, da, db);
     GD_LAUNCH_CHECK();
     return 0;
 }

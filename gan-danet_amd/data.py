@@ -99,13 +99,27 @@ class DeviceTileDataset:
     def batches(self, batch_size: int, rank: Optional[int] = None, world: Optional[int] = None
                 ) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
         """``DataLoader(dataset, batch_size=batch_size)`` (no shuffle, last batch kept, L133); with ``world`` > 1
-        ``batch_size`` is the GLOBAL batch and each rank gets its contiguous slice of it."""
+        ``batch_size`` is the GLOBAL batch and each rank gets its contiguous slice of it.
+
+        Under ``world`` > 1 every rank must run the SAME number of steps (each step issues collectives) and hold
+        shards of EQUAL size (per-shard means are averaged over ranks): a global batch is cut into ``world`` equal
+        shards and the ``len % world`` samples of a ragged last batch that do not fill one more round are dropped
+        (a last batch smaller than ``world`` is dropped whole).  ``batch_plan`` returns the same slices."""
         rank = _rank() if rank is None else rank
         world = _world() if world is None else world
-        n = len(self)
+        for lo, hi in self.batch_plan(batch_size, rank, world):
+            yield self.get(lo, hi)
+
+    def batch_plan(self, batch_size: int, rank: int, world: int) -> List[Tuple[int, int]]:
+        """[lo, hi) sample ranges of ``batches`` for one rank: one entry per step, equal length on every rank"""
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError(f"rank {rank} / world {world}")
+        if world > 1 and batch_size % world:
+            raise ValueError(f"global batch {batch_size} is not a multiple of the world size {world}")
+        plan, n = [], len(self)
         for g0 in range(0, n, batch_size):
             g1 = min(n, g0 + batch_size)
-            per = -(-(g1 - g0) // world)
-            lo, hi = min(g1, g0 + rank * per), min(g1, g0 + (rank + 1) * per)
-            if hi > lo:
-                yield self.get(lo, hi)
+            per = (g1 - g0) // world            # world == 1: the whole (possibly ragged) batch, as the reference
+            if per > 0:
+                plan.append((g0 + rank * per, g0 + (rank + 1) * per))
+        return plan

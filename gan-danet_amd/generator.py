@@ -180,9 +180,12 @@ class FlexibleUpsamplingModule(nn.Module):
         # (7x less HBM traffic there, no 64-channel 4H x 4W tensor kept for backward).  Same parameters, same
         # result up to fp32 re-association.
         w9 = fw.reshape(fw.shape[1], 9).t()                # (9, 64): w9[tap][ch]
-        t = ops.conv2d(c, w9.reshape(9, -1, 1, 1).contiguous())
+        t = ops.conv2d(c, w9.reshape(9, -1, 1, 1).contiguous())        # .t()/.reshape(): views + one layout copy
         u = up[7](t)                                       # (B, 9, 4H, 4W)
-        wk = [(w9 @ adj.weight.reshape(adj.weight.shape[0], -1)).reshape(9, -1, 1, 1).contiguous()
+        # composed operators (9 x C_k) = w9 (9 x 64) . A_k (64 x C_k): a 1x1 conv over A_k read as a 64-channel,
+        # C_k-pixel image (exact-fp32 MFMA kernel whatever the configured precision: these are weights)
+        w9c = w9.reshape(9, -1, 1, 1).contiguous()
+        wk = [ops.conv2d(adj.weight.reshape(1, adj.weight.shape[0], 1, -1), w9c, prec=ops.L.PREC_FP32).reshape(9, -1, 1, 1)
               for adj in self.channel_adjust]
         u = ops.SkipFuseFn.apply(u, *wk, *skips[::-1])
         return ops.ShiftSum9Fn.apply(u, self.final.bias)

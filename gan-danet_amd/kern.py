@@ -500,6 +500,30 @@ def bce_logits(z: Tensor, label: float, want_grad: bool):
     return out, dz
 
 
+def bce_logits_target(z: Tensor, t: Tensor, want_dz: bool, want_dt: bool):
+    _dense(z), _dense(t)
+    out = torch.empty(1, device=z.device, dtype=torch.float32)
+    dz = torch.empty_like(z) if want_dz else None
+    dt = torch.empty_like(t) if want_dt else None
+    L.check(lib().gd_bce_logits_target(_ptr(z), _ptr(t), z.numel(), _ptr(out), _ptr(dz), _ptr(dt),
+                                       _ptr(_red_ws(z.device)), _stream()), "gd_bce_logits_target")
+    return out, dz, dt
+
+
+def leaky_fwd(x: Tensor, slope: float) -> Tensor:
+    _dense(x)
+    y = torch.empty_like(x)
+    L.check(lib().gd_leaky_fwd(_ptr(x), _ptr(y), x.numel(), float(slope), _stream()), "gd_leaky_fwd")
+    return y
+
+
+def leaky_bwd(x: Tensor, dy: Tensor, slope: float) -> Tensor:
+    _dense(x), _dense(dy)
+    dx = torch.empty_like(x)
+    L.check(lib().gd_leaky_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), float(slope), _stream()), "gd_leaky_bwd")
+    return dx
+
+
 def diff_loss(kind: str, a: Tensor, b: Tensor, want_grad: bool):
     _dense(a), _dense(b)
     if a.shape != b.shape:
@@ -527,6 +551,28 @@ def ssim(a: Tensor, b: Tensor, window: int) -> Tensor:
     L.check(lib().gd_ssim(_ptr(a), _ptr(b), B * Cn, H, W, window, _ptr(out), _ptr(_red_ws(a.device)), _stream()),
             "gd_ssim")
     return out
+
+
+def ssim_samples(a: Tensor, b: Tensor, window: int) -> Tensor:
+    """per-sample SSIM means (B,)"""
+    _dense(a), _dense(b)
+    B, Cn, H, W = a.shape
+    out = torch.empty(B, device=a.device, dtype=torch.float32)
+    L.check(lib().gd_ssim_samples(_ptr(a), _ptr(b), B, Cn, H, W, window, _ptr(out), _ptr(_red_ws(a.device)), _stream()),
+            "gd_ssim_samples")
+    return out
+
+
+def ssim_bwd(a: Tensor, b: Tensor, gscale: Tensor, window: int, need_a: bool = True, need_b: bool = True):
+    """gradients of sum_s gscale[s] * sum_pixels ssim_map[s] w.r.t. a and b"""
+    _dense(a), _dense(b), _dense(gscale)
+    B, Cn, H, W = a.shape
+    coef = torch.empty(4 * a.numel(), device=a.device, dtype=torch.float32)
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(b) if need_b else None
+    L.check(lib().gd_ssim_bwd(_ptr(a), _ptr(b), _ptr(gscale), B, Cn, H, W, window, _ptr(coef), _ptr(da), _ptr(db),
+                              _stream()), "gd_ssim_bwd")
+    return da, db
 
 
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float, beta2: float, eps: float,
@@ -640,9 +686,11 @@ DETERMINISTIC = False
 
 
 def set_deterministic(on: bool) -> None:
-    """bitwise-reproducible kernels where a faster order-dependent form exists (PAM dQ: parts instead of atomics)"""
+    """bitwise-reproducible kernels wherever a faster order-dependent form exists: PAM dQ through bf16 parts instead of
+    fp32 atomics, split-K GEMMs and 3x3 weight gradients unsplit (gd_set_deterministic)"""
     global DETERMINISTIC
     DETERMINISTIC = bool(on)
+    lib().gd_set_deterministic(int(DETERMINISTIC))
 
 
 def pam_bwd_form() -> int:

@@ -12,7 +12,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d, square kernel / stride, zero padding, groups=1, dilation=1."""
+    """nn.Conv2d, square kernel / stride, zero padding, groups=1, dilation=1 -- every convolution of the reference's
+    models/ package is of this form (generator.py:20,34,63,108-110,148,188,214,218,222,228; discriminator.py:14-51,
+    62-65); other geometries are refused loudly rather than mis-computed."""
 
     def _geometry(self):
         k, s, p = self.kernel_size, self.stride, self.padding
@@ -76,14 +78,15 @@ class Sigmoid(nn.Module):
 
 
 class LeakyReLU(nn.Module):
+    """nn.LeakyReLU(negative_slope): 0.2 (every LeakyReLU of discriminator.py) is the fused-epilogue code, any other
+    slope runs the stand-alone kernel"""
+
     def __init__(self, negative_slope: float = 0.2, inplace: bool = False) -> None:
         super().__init__()
-        if abs(negative_slope - 0.2) > 1e-12:
-            raise NotImplementedError("only LeakyReLU(0.2) (the slope the reference uses)")
         self.negative_slope = negative_slope
 
     def forward(self, x):
-        return ops.activation(x, ACT_LEAKY)
+        return ops.leaky_relu(x, self.negative_slope)
 
 
 class UpsampleBicubic2x(nn.Module):

@@ -11,9 +11,12 @@ from torch import nn
 from . import ops
 from .layers import ACT_RELU, Conv2d, ReLU
 
-# torchvision.models.vgg19(...).features[:21] ("E" configuration): index -> layer
+# torchvision.models.vgg19(...).features ("E" configuration, 37 layers): index -> layer.  The reference keeps
+# features[: max(feature_layers) + 1] (losses.py:61); its default taps (1, 6, 11, 20) need the first 21.
 _VGG19_HEAD = ("c64", "r", "c64", "r", "p", "c128", "r", "c128", "r", "p",
-               "c256", "r", "c256", "r", "c256", "r", "c256", "r", "p", "c512", "r")
+               "c256", "r", "c256", "r", "c256", "r", "c256", "r", "p",
+               "c512", "r", "c512", "r", "c512", "r", "c512", "r", "p",
+               "c512", "r", "c512", "r", "c512", "r", "c512", "r", "p")
 
 
 class _MaxPool2(nn.Module):
@@ -36,7 +39,7 @@ class PerceptualLoss(nn.Module):
             raise ValueError("feature_layers must contain at least one index")
         top = max(self.feature_layers)
         if top >= len(_VGG19_HEAD):
-            raise ValueError("feature_layers beyond VGG19.features[:21] are not supported")
+            raise IndexError(f"VGG19.features has {len(_VGG19_HEAD)} layers; feature layer {top} does not exist")
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.device = device
@@ -135,7 +138,10 @@ class PerceptualLoss(nn.Module):
             w0 = self.vgg[0].weight.detach()
             plan = {"ops": ops_, "pairs": [tuple(p) for p in pairs], "taps": taps,
                     # 1-channel inputs are repeated to 3 channels (losses.py:65-68): conv(repeat(x)) = conv_{sum_c w}(x)
-                    "w0": {3: w0.contiguous(), 1: w0.sum(dim=1, keepdim=True).contiguous()}}
+                    # (the sum over the 3 input channels = a 1x1 conv with ones over the weight read as an image)
+                    "w0": {3: w0.contiguous(),
+                           1: K.conv2d_fwd(w0.contiguous(), torch.ones(1, w0.shape[1], 1, 1, device=w0.device), None, 1, 0,
+                                           K.L.PREC_FP32)}}
         self._nhwc_cache = (version, plan)
         return plan
 
@@ -225,33 +231,46 @@ class TVLoss(nn.Module):
 
 
 class SSIM(nn.Module):
-    """losses.py:90-147, forward value only (the train loop evaluates it and drops it, L263/L267).
-    ``size_average=False`` is not on the path and not implemented."""
+    """losses.py:90-147: Gaussian-window SSIM, differentiable w.r.t. both images (``gd_ssim_samples`` /
+    ``gd_ssim_bwd``); ``size_average=False`` returns one mean per sample (losses.py:136).  The window is rebuilt from
+    ``window_size`` inside the kernels exactly as ``_gaussian`` does (fp32 exp, normalised by the fp32 sum); the
+    ``window`` buffer is kept for ``state_dict`` / attribute parity with the reference."""
 
     def __init__(self, window_size: int = 11, size_average: bool = True) -> None:
         super().__init__()
         self.window_size = window_size
         self.size_average = size_average
         self.channel = 1
+        self.register_buffer("window", self._create_window(window_size, 1))
+
+    @staticmethod
+    def _create_window(window_size: int, channel: int) -> torch.Tensor:
         coords = torch.arange(window_size, dtype=torch.float32)
         g = torch.exp(-((coords - window_size // 2) ** 2) / (2 * 1.5 ** 2))
         g = (g / g.sum()).unsqueeze(1)
-        self.register_buffer("window", (g @ g.t()).unsqueeze(0).unsqueeze(0).contiguous())
+        return (g @ g.t()).unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous()
 
     def forward(self, img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
-        if not self.size_average:
-            raise NotImplementedError("SSIM(size_average=False) is not on the G+D path")
-        return ops.ssim_value(img1, img2, self.window_size)
+        channel = img1.shape[1]
+        if channel != self.channel:                       # losses.py:140-145: the buffer follows the channel count
+            self.register_buffer("window", self._create_window(self.window_size, channel).to(img1.device))
+            self.channel = channel
+        return ops.ssim(img1, img2, self.window_size, self.size_average)
 
 
 class BCEWithLogitsLoss(nn.Module):
-    """torch.nn.BCEWithLogitsLoss() for the all-ones / all-zeros targets the train loop uses (L249-253, L261)."""
+    """torch.nn.BCEWithLogitsLoss() (mean reduction): a constant label (the train loop's all-ones / all-zeros targets,
+    L249-253, L261) or a target tensor of the logits' shape."""
 
     def forward(self, logits: torch.Tensor, target) -> torch.Tensor:
-        label = float(target) if not torch.is_tensor(target) else None
-        if label is None:
-            raise NotImplementedError("pass the constant label (1.0 / 0.0); per-element targets are not on the path")
-        return ops.bce_with_logits(logits, label)
+        if torch.is_tensor(target):
+            if target.numel() == 1:
+                target = float(target)
+            else:
+                if target.shape != logits.shape:
+                    raise ValueError(f"target {tuple(target.shape)} must match the logits {tuple(logits.shape)}")
+                return ops.bce_with_logits_target(logits, target)
+        return ops.bce_with_logits(logits, float(target))
 
 
 class MSELoss(nn.Module):

@@ -40,8 +40,8 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # =====================================================================================================
 class Conv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride: int, pad: int, act: int):
-        prec = _prec()
+    def forward(ctx, x, w, bias, stride: int, pad: int, act: int, prec=None):
+        prec = _prec() if prec is None else prec
         y = K.conv2d_fwd(x, w, bias, stride, pad, prec, act=act)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, prec, bias is not None)
@@ -61,11 +61,12 @@ class Conv2dFn(Function):
             dw = K.conv2d_wgrad(dy, x, w.shape[2], stride, pad, prec)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.channel_sum(dy)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE):
-    return Conv2dFn.apply(x, w, bias, stride, pad, act)
+def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE, prec=None):
+    """``prec``: L.PREC_* override of the configured operand type (weight-space products stay exact fp32)"""
+    return Conv2dFn.apply(x, w, bias, stride, pad, act, prec)
 
 
 class ActFn(Function):
@@ -659,6 +660,48 @@ def bce_with_logits(z, label: float):
     return BceLogitsFn.apply(z, float(label))
 
 
+class BceLogitsTargetFn(Function):
+    """BCEWithLogitsLoss against a target tensor (mean reduction)"""
+
+    @staticmethod
+    def forward(ctx, z, t):
+        out, dz, dt = K.bce_logits_target(_c(z), _c(t), True, t.requires_grad)
+        ctx.save_for_backward(dz, dt if dt is not None else dz)
+        ctx.has_dt = dt is not None
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, dt = ctx.saved_tensors
+        g1 = _c(g).view(1)
+        return (K.scale_dev(dz, g1) if ctx.needs_input_grad[0] else None,
+                K.scale_dev(dt, g1) if (ctx.has_dt and ctx.needs_input_grad[1]) else None)
+
+
+def bce_with_logits_target(z, t):
+    return BceLogitsTargetFn.apply(z, t)
+
+
+class LeakyFn(Function):
+    """LeakyReLU with a slope other than the fused 0.2"""
+
+    @staticmethod
+    def forward(ctx, x, slope: float):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return K.leaky_fwd(x, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.leaky_bwd(x, _c(g), ctx.slope), None
+
+
+def leaky_relu(x, slope: float):
+    return activation(x, ACT_LEAKY) if abs(slope - 0.2) < 1e-12 else LeakyFn.apply(x, float(slope))
+
+
 def mse_loss(a, b):
     return MseFn.apply(a, b)
 
@@ -672,9 +715,56 @@ def tv_loss(x, weight: float):
 
 
 def ssim_value(a, b, window: int = 11):
-    """forward-only SSIM mean (the train loop evaluates it but never differentiates it)"""
+    """forward-only SSIM mean: the trainer's explicit no-grad evaluation (the reference computes 1 - SSIM at L263 and
+    never adds it to loss_G)"""
     with torch.no_grad():
         return K.ssim(_c(a), _c(b), window).view(())
+
+
+class SsimFn(Function):
+    """SSIM._ssim (losses.py:109-136), differentiable w.r.t. both images.  Returns the per-sample means (B,)."""
+
+    @staticmethod
+    def forward(ctx, a, b, window: int):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        ctx.window = window
+        return K.ssim_samples(a, b, window)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        n = a[0].numel()
+        gs = torch.empty_like(_c(g))
+        K.axpby(_c(g), 1.0 / n, gs, 0.0)                      # d(mean over C,H,W) of a sample's map
+        da, db = K.ssim_bwd(a, b, gs, ctx.window, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db, None
+
+
+def ssim(a, b, window: int = 11, size_average: bool = True):
+    """SSIM.forward (losses.py:138-147): mean of the SSIM map (size_average) or one mean per sample"""
+    per_sample = SsimFn.apply(a, b, window)
+    return mean_of(per_sample) if size_average else per_sample
+
+
+class MeanFn(Function):
+    """mean of a small device vector (composition of the per-sample losses; no host sync)"""
+
+    @staticmethod
+    def forward(ctx, v):
+        v = _c(v)
+        ctx.n = v.numel()
+        out = K.dot(v, None)                                  # sum
+        return K.axpby(out, 1.0 / ctx.n, torch.empty_like(out), 0.0).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        w = torch.full((ctx.n,), 1.0 / ctx.n, device=g.device, dtype=torch.float32)
+        return K.scale_dev(w, _c(g).view(1))
+
+
+def mean_of(v):
+    return MeanFn.apply(v)
 
 
 class AddScalarsFn(Function):

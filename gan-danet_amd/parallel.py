@@ -62,6 +62,7 @@ class GradReducer:
         self._flat = {}
         self._early = {}            # id(param) -> Work of an all-reduce already in flight for this backward
         self._hooks = []
+        self._world = world_size()      # hooks are registered (or not) for THIS world: reduce() checks it still holds
         if is_distributed():
             for p in self.params:
                 if isinstance(p, torch.nn.parameter.UninitializedParameter):
@@ -82,6 +83,9 @@ class GradReducer:
 
     @torch.no_grad()
     def reduce(self) -> None:
+        if world_size() != self._world:
+            raise RuntimeError(f"GradReducer was built for world size {self._world}, torch.distributed now reports "
+                               f"{world_size()}: build it after init_process_group")
         if not is_distributed():
             return
         early_ids = set(self._early.keys())           # big tensors whose all-reduce started during the backward

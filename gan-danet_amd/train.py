@@ -52,6 +52,7 @@ class GanTrainer:
         # reduce_gradients=False: this process trains an INDEPENDENT replica (an ensemble member, checkpoint.py) even
         # when torch.distributed is initialised -- no gradient exchange, no 1/world scaling
         ws = world_size() if reduce_gradients else 1
+        self._reduce = reduce_gradients
         self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
         self.opt_g = AdamW(g_params, lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
         self.red_d = GradReducer(D.parameters()) if reduce_gradients else _NoReduce()
@@ -61,7 +62,12 @@ class GanTrainer:
         # per-shard oracle computes it); set tv_global_batch_semantics to scale it back by 1/world.
         self.tv_weight = tv_weight / ws if tv_global_batch_semantics else tv_weight
         self.compute_ssim = compute_ssim
-        self.batch_real_fake = batch_real_fake
+        # D(cat[real, fake]) == (D(real), D(fake)) only for a discriminator WITHOUT batch statistics: with BatchNorm
+        # (SRGAND has ten) the mixed batch would change the statistics and update the running stats once instead
+        # of twice (the reference calls D separately, L247-248) -- such a D always takes the two-pass form
+        self._d_has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in D.modules())
+        self.batch_real_fake = batch_real_fake and not self._d_has_bn
+        self._world = ws                       # the world this trainer's 1/world gradient scale was built for
 
     def step_from_batch(self, lr_grace_05: torch.Tensor, lr_grace_025: torch.Tensor, hr_aux: torch.Tensor,
                         loss_weight: float) -> StepOutput:
@@ -72,13 +78,17 @@ class GanTrainer:
 
     def step(self, x: torch.Tensor, target: torch.Tensor, loss_weight: float) -> StepOutput:
         G, D = self.G, self.D
+        if self._reduce and world_size() != self._world:
+            raise RuntimeError(f"GanTrainer was built for world size {self._world} but torch.distributed now reports "
+                               f"{world_size()}: construct the trainer AFTER init_process_group (its AdamW gradient "
+                               "scale and all-reduce hooks are fixed at construction)")
         hr = G(x if self.input_attention is None else self.input_attention(x))
 
         # ---- discriminator update (L246-256) ----
         self.opt_d.zero_grad(set_to_none=True)
         if self.batch_real_fake and target.shape == hr.shape:
-            # D has no BatchNorm, so D(cat[real, fake]) == (D(real), D(fake)) exactly; one pass streams fc1's
-            # weights once per forward / data-gradient / weight-gradient instead of twice
+            # D has no BatchNorm (checked in __init__), so D(cat[real, fake]) == (D(real), D(fake)) exactly; one pass
+            # streams fc1's weights once per forward / data-gradient / weight-gradient instead of twice
             nb = target.shape[0]
             both = torch.empty((2 * nb,) + tuple(target.shape[1:]), device=target.device, dtype=torch.float32)
             K.copy_slab(target if target.is_contiguous() else target.contiguous(), both[:nb])

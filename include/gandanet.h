@@ -26,6 +26,10 @@ extern "C" {
 #endif
 
 #define GD_VERSION 100 /* 0.1.0 */
+/* deterministic mode (process-global): on = every reduction in a fixed order (split-K GEMM and the 3x3 weight
+ * gradient run unsplit instead of combining partial sums with fp32 atomics) -- bitwise reproducible, slower. */
+void gd_set_deterministic(int on);
+int gd_get_deterministic(void);
 int gd_version(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
 int gd_last_error(char* buf, int n);
@@ -212,6 +216,13 @@ int gd_add_transpose(const float* a, float* out, int B, int n, void* stream);
 /* losses: value -> out[0] (fp32), gradient written when the pointer is non-NULL.  ws >= 2048 floats.
  * BCEWithLogits mean vs a constant label (GAN_DANet_train.ipynb:L190,L252-253,L261) */
 int gd_bce_logits(const float* z, long n, float label, float* out, float* dz, float* ws, void* stream);
+/* the same against a per-element target tensor t (n); dz / dt (either may be NULL): gradients of the mean */
+int gd_bce_logits_target(const float* z, const float* t, long n, float* out, float* dz, float* dt, float* ws,
+                         void* stream);
+/* LeakyReLU with an arbitrary negative slope (the fused conv / linear epilogues implement the reference's 0.2 only);
+ * backward takes the INPUT x. */
+int gd_leaky_fwd(const float* x, float* y, long n, float slope, void* stream);
+int gd_leaky_bwd(const float* x, const float* dy, float* dx, long n, float slope, void* stream);
 /* MSELoss / L1 mean (L191,L262; losses.py:72) */
 int gd_mse(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream);
 int gd_l1(const float* a, const float* b, long n, float* out, float* da, float* ws, void* stream);
@@ -219,6 +230,14 @@ int gd_l1(const float* a, const float* b, long n, float* out, float* da, float* 
 int gd_tv(const float* x, int B, int C, int H, int W, float weight, float* out, float* dx, float* ws, void* stream);
 /* SSIM mean (losses.py:109-136), forward only (the train loop never differentiates it) */
 int gd_ssim(const float* a, const float* b, int BC, int H, int W, int window, float* out, float* ws, void* stream);
+/* per-sample SSIM means (SSIM(size_average=False), losses.py:136): out (B) */
+int gd_ssim_samples(const float* a, const float* b, int B, int C, int H, int W, int window, float* out, float* ws,
+                    void* stream);
+/* SSIM backward (losses.py:118-136 under autograd): gscale (B) = upstream gradient of each sample's pixels (already
+ * divided by the element count of the mean); coef_ws: caller-owned scratch of 4 * B*C*H*W floats; da / db (either may
+ * be NULL): gradients w.r.t. img1 / img2, overwritten. */
+int gd_ssim_bwd(const float* a, const float* b, const float* gscale, int B, int C, int H, int W, int window,
+                float* coef_ws, float* da, float* db, void* stream);
 
 /* AdamW step over one tensor (torch.optim.AdamW, GAN_DANet_train.ipynb:L182-183).
  * `step` is 1-based.  The gradient is read once, multiplied by grad_scale (1/world for DP). */

@@ -112,3 +112,25 @@ def test_oracle_reference_state_dict_loads_into_product_modules():
     assert not missing and not unexpected
     back = OM.FlexibleUpsamplingModule(input_channels=8)
     back.load_state_dict(G.state_dict(), strict=True)
+
+
+def test_batch_plan_gives_every_rank_the_same_steps():
+    """ranks must not run different numbers of steps per epoch (their collectives would pair across
+    steps).  n=100, global batch 32, world 8: four steps would leave ranks 4-7 without a shard in the last one."""
+    from gan_danet_amd.data import DeviceTileDataset
+
+    class _Fake:
+        def __len__(self):
+            return 100
+    plans = [DeviceTileDataset.batch_plan(_Fake(), 32, r, 8) for r in range(8)]
+    assert len({len(p) for p in plans}) == 1 and len(plans[0]) == 3      # 4-sample tail (< 8 ranks) dropped
+    sizes = {hi - lo for p in plans for lo, hi in p}
+    assert sizes == {4}
+    # shards of one step tile the global batch without overlap
+    for step in range(3):
+        spans = sorted(p[step] for p in plans)
+        assert spans[0][0] == 32 * step and all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    # world 1 keeps the reference loader's ragged last batch
+    assert DeviceTileDataset.batch_plan(_Fake(), 32, 0, 1)[-1] == (96, 100)
+    with pytest.raises(ValueError):
+        DeviceTileDataset.batch_plan(_Fake(), 30, 0, 8)

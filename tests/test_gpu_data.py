@@ -66,15 +66,22 @@ def test_dataset_batches_match_reference_restatement(augment):
 
 
 def test_rank_shards_partition_each_global_batch():
+    """every rank runs the same number of steps with shards of equal size (each step issues collectives, per-shard
+    means are averaged over ranks); the ranks' shards of a step are consecutive slices of the global batch"""
     from gan_danet_amd.data import DeviceTileDataset
     a, b, c = _arrays(n=10)
     ds = DeviceTileDataset(a, b, c, device=DEV)
     full = list(ds.batches(8, rank=0, world=1))
+    assert [len(fb[0]) for fb in full] == [8, 2]            # world 1: the reference's loader, ragged tail kept
     parts = [list(ds.batches(8, rank=r, world=4)) for r in range(4)]
-    for i, fb in enumerate(full):
-        pieces = [p[i] for p in parts if i < len(p)]
+    assert len({len(p) for p in parts}) == 1                # same step count on every rank
+    assert [len(pb[0]) for pb in parts[0]] == [2]           # the 2-sample tail cannot fill 4 ranks: dropped
+    for i in range(len(parts[0])):
         for col in range(3):
-            assert torch.equal(torch.cat([pc[col] for pc in pieces]), fb[col])
+            got = torch.cat([p[i][col] for p in parts])
+            assert torch.equal(got, full[i][col][:len(got)])
+    parts2 = [list(ds.batches(8, rank=r, world=2)) for r in range(2)]
+    assert [[len(pb[0]) for pb in p] for p in parts2] == [[4, 1], [4, 1]]
 
 
 def test_loader_batch_feeds_the_trainer_step():

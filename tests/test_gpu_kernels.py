@@ -234,6 +234,12 @@ def test_losses(gd, golden_dir):
     assert_close(tv, fx["tv"], 1e-5, "tv")
     assert_close(g, fx["gtv"], 1e-5, "dtv")
     assert_close(ops.ssim_value(a, b, 11), fx["ssim"], 1e-4, "ssim")
+    # differentiable SSIM (reference fixture: value and gradient w.r.t. img1 from losses.SSIM(11, True))
+    ss = ops.ssim(a, b, 11, True)
+    assert ss.requires_grad
+    (gs,) = torch.autograd.grad(ss, a)
+    assert_close(ss, fx["ssim"], 1e-4, "ssim (differentiable)")
+    assert_close(gs, fx["gssim"], 1e-4, "dssim/dimg1 vs reference fixture", rell2)
     z = fx["z"].to(DEV).requires_grad_(True)
     l1 = ops.bce_with_logits(z, 1.0)
     assert_close(l1, fx["bce1"], 1e-5, "bce1")
@@ -454,3 +460,88 @@ def test_shift_sum9_is_the_one_hot_3x3_conv(gd):
     assert_close(y, yr, 1e-6, "y")
     assert_close(ug.grad, ur.grad, 1e-7, "du")
     assert_close(bg.grad, br.grad, 1e-5, "dbias")
+
+
+@pytest.mark.parametrize("shape,size_average", [((2, 3, 24, 20), False), ((3, 1, 40, 33), True)])
+def test_ssim_module_gradients_vs_oracle(gd, shape, size_average):
+    """SSIM drop-in (losses.py:90-147): both reductions, multi-channel windows, gradients w.r.t. BOTH images, through
+    the exported module and a weighted upstream -- against the oracle's autograd (fp64)"""
+    import gan_danet_amd as G
+    from oracle import functional as OF
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(shape, generator=g) * 2 - 1
+    b = (a + 0.3 * torch.randn(shape, generator=g)).clamp(-1.5, 1.5)
+    w = torch.rand(shape[0], generator=g) + 0.5
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = OF.ssim(ar, br, 11, size_average)
+    (ref * (w.double() if not size_average else 1.0)).sum().backward()
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    m = G.SSIM(11, size_average).to(DEV)
+    out = m(ad, bd)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close(out, ref.float(), 1e-4, "ssim value")
+    if size_average:
+        out.backward()
+    else:
+        out.backward(w.to(DEV))
+    assert_close(ad.grad, ar.grad.float(), 2e-4, "dssim/dimg1", rell2)
+    assert_close(bd.grad, br.grad.float(), 2e-4, "dssim/dimg2", rell2)
+    assert m.window.shape == (shape[1], 1, 11, 11)
+
+
+def test_bce_target_tensor_and_general_leaky_slope(gd):
+    """API width of the drop-in criteria / activations: BCEWithLogitsLoss with a target TENSOR and
+    LeakyReLU with a slope other than the fused 0.2, against ATen on the CPU"""
+    import gan_danet_amd as G
+    from gan_danet_amd.layers import LeakyReLU
+    z = seeded((6, 1), 71)
+    t = torch.rand(6, 1, generator=torch.Generator().manual_seed(72))
+    zr, tr = z.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(zr, tr)
+    ref.backward()
+    zd, td = z.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+    out = G.BCEWithLogitsLoss()(zd, td)
+    out.backward()
+    assert_close(out, ref.detach(), 1e-6, "bce(target tensor)")
+    assert_close(zd.grad, zr.grad, 1e-5, "dbce/dz")
+    assert_close(td.grad, tr.grad, 1e-5, "dbce/dt")
+    assert_close(G.BCEWithLogitsLoss()(zd.detach(), torch.ones(())), F.binary_cross_entropy_with_logits(z, torch.ones_like(z)), 1e-6, "0-dim target")
+    for slope in (0.01, 0.2, 0.0):
+        x = seeded((3, 5, 7, 4), 73)
+        xr = x.clone().requires_grad_(True)
+        yr = F.leaky_relu(xr, slope)
+        go = seeded(tuple(x.shape), 74)
+        yr.backward(go)
+        xd = x.to(DEV).requires_grad_(True)
+        yd = LeakyReLU(slope)(xd)
+        yd.backward(go.to(DEV))
+        assert torch.equal(yd.cpu(), yr.detach()) and torch.equal(xd.grad.cpu(), xr.grad), f"LeakyReLU({slope})"
+
+
+def test_deterministic_mode_makes_split_reductions_reproducible(gd):
+    """gd.set_deterministic(True): the 3x3 weight gradient and the split-K NT GEMM (fp32 atomics across splits by
+    default) run unsplit -- two launches agree bit for bit and match the default mode to fp32 round-off"""
+    ops, K = _ops()
+    from gan_danet_amd import _lib as L
+    x = seeded((4, 64, 96, 96), 81).to(DEV)
+    dy = seeded((4, 24, 96, 96), 82).to(DEV)
+    a = seeded((8, 200000), 83).to(DEV)
+    bm = seeded((24, 200000), 84).to(DEV)
+
+    def run():
+        dw = K.conv2d_wgrad(dy, x, 3, 1, 1, L.PREC_BF16)
+        c = torch.empty(1, 8, 24, device=DEV)
+        K.gemm_nt(B=1, M=8, N=24, kseg=1, klen=200000, a=a, a_bs=a.numel(), a_ss=0, lda=200000, bm=bm, b_bs=bm.numel(), b_ss=0,
+                  ldb=200000, c=c, c_bs=8 * 24, ldc=24, precision=L.PREC_FP32)
+        return dw.clone(), c.clone()
+
+    base = run()
+    gd.set_deterministic(True)
+    try:
+        assert L.load().gd_get_deterministic() == 1
+        d1, d2 = run(), run()
+    finally:
+        gd.set_deterministic(False)
+    assert torch.equal(d1[0], d2[0]) and torch.equal(d1[1], d2[1])
+    assert_close(d1[0], base[0].cpu(), 1e-5, "deterministic vs default wgrad", rell2)
+    assert_close(d1[1], base[1].cpu(), 1e-5, "deterministic vs default split-K", rell2)
