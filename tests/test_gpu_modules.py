@@ -216,13 +216,119 @@ def test_generator_vs_reference_fixture(gd, golden_dir, prec):
             ye = G(x)
         assert_close(ye, load_golden(golden_dir, "generator_8ch_16x16_eval")["y"], 1e-3, "eval y")
     else:
-        assert_close(y, fx["y"], 5e-2, "y bf16", rell2)
-        # dL/dx through the three attention blocks has condition number ~1e2 (test_oracle_golden.py), so
-        # bf16 operand rounding (4e-3) alone moves it by O(1): only direction/size sanity is asserted here;
-        # the bf16 kernels' gradients are pinned op by op (conv, linear, PAM tests above).
-        g, gr = x.grad.cpu().double().flatten(), fx["gx"].double().flatten()
-        cos = (g @ gr / (g.norm() * gr.norm())).item()
-        assert cos > 0.5 and 0.3 < (g.norm() / gr.norm()).item() < 3.0, f"bf16 dx cosine {cos:.3f}"
+        # bf16 operands (the timed mode): measured 2.4e-2 rel-L2 / 3.6e-2 max (profiles/r02_parity_report.json) -- every
+        # one of the ~35 GEMM-shaped layers rounds its operands to 8 significant bits.  The 1e-3 north-star bound is the
+        # fp32 mode's; bench.py prints this number as "g_out_rel_err" next to the throughput.
+        assert_close(y, fx["y"], 4e-2, "y bf16", rell2)
+        assert_close(y, fx["y"], 6e-2, "y bf16 max")
+        # gradients of this fixture in bf16: see test_generator_16bit_gradients_at_bench_init_vs_oracle
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_generator_16bit_gradients_at_bench_init_vs_oracle(gd, prec):
+    """The timed (bf16) mode and the config-5 (fp16 PAM operands) mode at MODEL level, gradients included: whole
+    generator with the bench's initialisation (weights_init_normal, gamma = 0.1), 8 channels, 32 x 32 tiles, B = 2,
+    against the fp64 oracle -- output, input gradient and EVERY parameter gradient (rel-L2 each).
+    Bounds = 1.5x the measured errors (tools/parity_report.py -> profiles/r02_parity_report.json: y 2.1e-2, dx 0.28,
+    parameter gradients median 0.28, worst 0.75-0.87).  They are what bf16 rounding (2^-8) times the conditioning of
+    the three attention blocks (~1e2, tests/test_oracle_golden.py) gives, not round-off-tight: the op-level tests pin
+    each bf16 kernel to ~3e-3."""
+    from oracle import modules as OM
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 32, 32, generator=g)
+    mo = OM.FlexibleUpsamplingModule(input_channels=8).double()
+    torch.manual_seed(11)
+    mo.apply(OM.weights_init_normal)
+    for n, p in mo.named_parameters():
+        if n.endswith("gamma"):
+            p.data.fill_(0.1)
+    xo = x.double().requires_grad_(True)
+    yo = mo.train()(xo)
+    go = torch.randn(yo.shape, generator=g)
+    yo.backward(go.double())
+    mp = gd.FlexibleUpsamplingModule(input_channels=8)
+    mp.load_state_dict({k: v.float() for k, v in mo.state_dict().items()})
+    mp.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    with gd.precision(prec):
+        y = mp(xd)
+        y.backward(go.to(DEV))
+    assert_close(y, yo.float(), 3.5e-2, f"y {prec}", rell2)
+    assert_close(xd.grad, xo.grad.float(), 0.45, f"dx {prec}", rell2)
+    po = dict(mo.named_parameters())
+    errs = {n: rell2(p.grad, po[n].grad.float()) for n, p in mp.named_parameters()
+            if not n.endswith("key.bias") and po[n].grad.norm() > 0}
+    assert len(errs) >= 90
+    med = sorted(errs.values())[len(errs) // 2]
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert med <= 0.42, f"median parameter-gradient error {med:.3f}"
+    assert worst[1] <= 1.3, f"worst parameter gradient {worst}"
+    # direction: every gradient tensor points the reference's way
+    for n, p in mp.named_parameters():
+        if n in errs and errs[n] > 0.5:
+            a, b = p.grad.double().flatten().cpu(), po[n].grad.flatten()
+            assert (a @ b) / (a.norm() * b.norm()) > 0.5, n
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_danet_16bit_vs_reference_fixture(gd, golden_dir, prec):
+    """DANetAttention(64) fixture in the 16-bit operand modes (measured bf16: y 2.4e-3, dx 4.4e-2, parameter gradients
+    <= 0.12; fp16: 2.4e-3 / 4.6e-2 / 0.09)"""
+    from gan_danet_amd.generator import DANetAttention
+    fx = load_golden(golden_dir, "danet_c64_16x16")
+    m = DANetAttention(64)
+    fill_module(m)
+    m.to(DEV).train()
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with gd.precision(prec):
+        y = m(x)
+        y.backward(fx["go"].to(DEV))
+    assert_close(y, fx["y"], 6e-3, "y", rell2)
+    assert_close(x.grad, fx["gx"], 9e-2, "dx", rell2)
+    _check_param_grads(m, fx, 0.25, rell2, zero_tol=0.2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_config2_danet64_and_cam_at_128x128_vs_fp64_oracle(gd, prec):
+    """BASELINE config 2 -- DANetAttention(64) on a 128 x 128 x 64 feature map (PAM over N = 16 384 tokens, CAM's Gram
+    matrix reduced over 16 384 pixels, the fuse conv) -- forward AND backward against the fp64 oracle, and CAMModule(64)
+    alone at that size (its logits scale with N: the precision-sensitive op).
+    Bounds ~2-3x the measured errors (profiles/r02_parity_report.json)."""
+    from gan_danet_amd.generator import CAMModule, DANetAttention
+    from oracle import modules as OM
+    tol = {"fp32": dict(y=1e-5, dx=2e-5, pg=3e-4, cy=5e-6, cdx=3e-4),
+           "bf16": dict(y=6e-3, dx=6e-2, pg=0.12, cy=2e-3, cdx=6e-3),
+           "fp16": dict(y=6e-3, dx=7e-2, pg=0.12, cy=2e-3, cdx=6e-3)}[prec]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 128, 128, generator=g)
+    for kind in ("danet", "cam"):
+        mo = (OM.DANetAttention(64) if kind == "danet" else OM.CAMModule(64)).double()
+        if kind == "danet":
+            fill_module(mo)
+        else:
+            mo.gamma.data.fill_(0.3)
+        xo = x.double().requires_grad_(True)
+        yo = mo.train()(xo)
+        go = torch.randn(yo.shape, generator=g)
+        yo.backward(go.double())
+        mp = DANetAttention(64) if kind == "danet" else CAMModule(64)
+        mp.load_state_dict({k: v.float() for k, v in mo.state_dict().items()})
+        mp.to(DEV).train()
+        xd = x.to(DEV).requires_grad_(True)
+        with gd.precision(prec):
+            y = mp(xd)
+            y.backward(go.to(DEV))
+        assert_close(y, yo.float(), tol["y"] if kind == "danet" else tol["cy"], f"{kind} y", rell2)
+        assert_close(xd.grad, xo.grad.float(), tol["dx"] if kind == "danet" else tol["cdx"], f"{kind} dx", rell2)
+        po = dict(mo.named_parameters())
+        errs = {n: rell2(p.grad, po[n].grad.float()) for n, p in mp.named_parameters()
+                if not n.endswith("key.bias") and not n.endswith("position_attention.gamma")}
+        med = sorted(errs.values())[len(errs) // 2]
+        assert med <= tol["pg"], f"{kind} median parameter-gradient error {med:.2e}: {errs}"
+        if kind == "danet" and prec == "fp32":
+            # d/dgamma of PAM is a heavily cancelling sum (|value| << sum |terms|): pinned in the exact mode only
+            e = rell2(mp.position_attention.gamma.grad, po["position_attention.gamma"].grad.float())
+            assert e <= 1e-3, f"PAM gamma gradient {e:.2e}"
 
 
 def test_state_dict_roundtrip_with_reference_keys(gd, golden_dir):

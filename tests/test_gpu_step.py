@@ -36,8 +36,9 @@ def test_three_step_trajectory_fp32(golden_dir):
             dn = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in D.parameters())))
             assert abs(dn - fx["d_norm"][i].item()) <= 1e-5 * dn
         # AdamW's first steps are sign-like (g/|g|): elements whose gradient is at round-off level move by
-        # +-lr in either implementation, so outputs after 3 steps agree to ~5e-2, not to round-off
-        assert_close(out.hr, fx["hr_last"], 1.5e-1, "hr after 3 steps", rell2)
+        # +-lr in either implementation, so outputs after 3 steps agree to ~5e-2, not to round-off.  Measured
+        # 6.2e-2 (profiles/r02_parity_report.json; the CPU oracle itself is held to 2e-2 against the same fixture)
+        assert_close(out.hr, fx["hr_last"], 1.0e-1, "hr after 3 steps", rell2)
         assert_close(G.final.weight, fx["final_w"], 5e-4, "final.weight", rell2)  # same sign-like-update effect
     # D weight grads are not formed in the G step, G's are
     assert all(p.grad is not None for p in G.parameters())
