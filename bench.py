@@ -8,6 +8,13 @@ passes, TV + perceptual(VGG19 random-init) + MSE + BCE losses, SSIM evaluation, 
 synthetic 8-channel 256x256 tiles -> 1024x1024, batch 32 per GPU (BASELINE.json configs[2]; config 3 of
 SURVEY.md 8d), bf16 MFMA operands / fp32 accumulate and storage.  Weak scaling: per-GPU batch fixed,
 gradients all-reduced with RCCL.  Prints ONE JSON line on rank 0.
+
+--config selects the other measured configurations of SURVEY.md 8d (default 3 = the metric's own):
+    2   DANetAttention(64) FORWARD on a (B, 64, 128, 128) feature map, bf16 (attention bring-up; step = one forward)
+    3/4 the full G+D step (4 = the same under torchrun with N ranks)
+    5   512x512 tiles, fp16 PAM operands, N = 262 144 tokens: generator forward + backward + AdamW (MSE + TV loss);
+        the discriminator is EXCLUDED (its fc1 alone is 8.6 G parameters = 137 GB with gradient and AdamW state) --
+        stated in config.workload
 """
 from __future__ import annotations
 
@@ -32,10 +39,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
-    ap.add_argument("--tile", type=int, default=256, help="generator input tile (BASELINE config: 256)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="SURVEY.md 8d configuration")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (config 3: 32, config 2: 32, config 5: 1)")
+    ap.add_argument("--tile", type=int, default=None, help="generator input tile (config 3: 256, 2: 128, 5: 512)")
     ap.add_argument("--channels", type=int, default=8)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-perceptual", action="store_true", help="exploration only; the reported config has it on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
@@ -85,8 +93,31 @@ def cpu_baseline(nsteps: int):
                       f"perceptual term with random VGG19) by the CPU oracle; {dt / nsteps:.2f} s/step"}
 
 
+def g_out_rel_err(gd, dev, precision):
+    """generator output error of the timed operand mode on the REFERENCE fixture (tests/golden/generator_8ch_16x16.npz,
+    generated from /root/reference/models/generator.py by tests/golden/make_golden.py): the north-star quantity"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from fill import fill_module
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "generator_8ch_16x16.npz"))
+    Gf = gd.FlexibleUpsamplingModule(input_channels=8)
+    fill_module(Gf)
+    Gf.to(dev).train()
+    with torch.no_grad(), gd.precision(precision):
+        y = Gf(torch.from_numpy(fx["x"]).to(dev)).double().cpu()
+    ref = torch.from_numpy(fx["y"]).double()
+    return {"fixture": "tests/golden/generator_8ch_16x16.npz (output of the reference generator)",
+            "rel_l2": float((y - ref).norm() / ref.norm()), "rel_max": float((y - ref).abs().max() / ref.abs().max()),
+            "north_star": "1e-3 (held by --precision fp32: 4e-6; 16-bit operand modes: see profiles/r02_parity_report.json)"}
+
+
 def main():
     args = parse()
+    cfg = args.config
+    defaults = {2: (32, 128, "bf16"), 3: (32, 256, "bf16"), 4: (32, 256, "bf16"), 5: (1, 512, "fp16")}[cfg]
+    args.batch = defaults[0] if args.batch is None else args.batch
+    args.tile = defaults[1] if args.tile is None else args.tile
+    args.precision = defaults[2] if args.precision is None else args.precision
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,39 +134,94 @@ def main():
 
     import gan_danet_amd as gd
     from gan_danet_amd import kern
-    from gan_danet_amd.parallel import broadcast_module
+    from gan_danet_amd.parallel import GradReducer, broadcast_module, world_size
 
     gd.set_precision(args.precision)
     B, T, Cin = args.batch, args.tile, args.channels
-
-    # ---- models (random init of the reference architecture; no checkpoints offline) ----
-    torch.manual_seed(1234)
-    G = gd.FlexibleUpsamplingModule(input_channels=Cin).to(dev)
-    D = gd.Discriminator1().to(dev)
-    with torch.no_grad():
-        D(torch.zeros(1, 1, 4 * T, 4 * T, device=dev))          # materialise LazyLinear fc1
-    G.apply(gd.weights_init_normal)
-    D.apply(gd.weights_init_normal)
-    for n, p in G.named_parameters():
-        if n.endswith("gamma"):
-            p.data.fill_(0.1)                                     # attention active (reference init is 0)
-    perc = None
-    if not args.no_perceptual:
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            perc = gd.PerceptualLoss(pretrained=False, device=dev)
-    broadcast_module(G)
-    broadcast_module(D)
-    if perc is not None:
-        broadcast_module(perc)
-    G.train()
-    D.train()
-    trainer = gd.GanTrainer(G, D, perceptual=perc)
-
-    # ---- synthetic shard, resident in HBM before the timed region ----
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(B, Cin, T, T, device=dev, generator=gen)
-    target = torch.randn(B, 1, 4 * T, 4 * T, device=dev, generator=gen)
+    torch.manual_seed(1234)
+    perc = None
+    extra = {}
+
+    if cfg == 2:
+        # ---- BASELINE config 2: DANetAttention(64) forward on (B, 64, T, T) ----
+        from gan_danet_amd.generator import DANetAttention
+        C2 = 64
+        A = DANetAttention(C2).to(dev)
+        A.apply(gd.weights_init_normal)
+        for n, p in A.named_parameters():
+            if n.endswith("gamma"):
+                p.data.fill_(0.1)
+        broadcast_module(A)
+        A.train()
+        x = torch.randn(B, C2, T, T, device=dev, generator=gen)
+
+        def step():
+            with torch.no_grad():
+                return A(x)
+        workload = (f"DANetAttention({C2}) forward (PAM N={T * T} d_qk={C2 // 8} + CAM + fuse conv3x3/BN/ReLU) on "
+                    f"({B},{C2},{T},{T}), batch {B}/GPU")
+        metric = f"attention-forward samples/sec, DANetAttention(64) on {T}x{T}x64 feature maps"
+    elif cfg == 5:
+        # ---- BASELINE config 5: 512x512 tiles, fp16 PAM operands; G forward + backward + AdamW, D excluded ----
+        G = gd.FlexibleUpsamplingModule(input_channels=Cin).to(dev)
+        G.apply(gd.weights_init_normal)
+        for n, p in G.named_parameters():
+            if n.endswith("gamma"):
+                p.data.fill_(0.1)
+        broadcast_module(G)
+        G.train()
+        from gan_danet_amd import ops
+        opt = gd.AdamW(G.parameters(), lr=2e-4, betas=(0.5, 0.999), weight_decay=1e-4, grad_scale=1.0 / world_size())
+        red = GradReducer(G.parameters())
+        x = torch.randn(B, Cin, T, T, device=dev, generator=gen)
+        target = torch.randn(B, 1, 4 * T, 4 * T, device=dev, generator=gen)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            hr = G(x)
+            loss = ops.weighted_sum([1.0, 1.0], [ops.mse_loss(hr, target), ops.tv_loss(hr, 1e-5)])
+            loss.backward()
+            red.reduce()
+            opt.step()
+            return loss.detach()
+        workload = (f"generator forward + backward + AdamW (MSE + TV loss), {Cin}ch {T}x{T} -> {4 * T}x{4 * T} tiles, "
+                    f"PAM N={T * T} tokens with fp16 MFMA operands, batch {B}/GPU (global {B * world}); discriminator "
+                    f"EXCLUDED (Discriminator1.fc1 at this tile = 8.6e9 parameters = 137 GB with gradient + AdamW state)")
+        metric = f"generator train samples/sec on {T}x{T} tiles (PAM N={T * T}), discriminator excluded"
+    else:
+        # ---- BASELINE config 3 / 4: the full G+D step (the metric's own configuration) ----
+        G = gd.FlexibleUpsamplingModule(input_channels=Cin).to(dev)
+        D = gd.Discriminator1().to(dev)
+        with torch.no_grad():
+            D(torch.zeros(1, 1, 4 * T, 4 * T, device=dev))          # materialise LazyLinear fc1
+        G.apply(gd.weights_init_normal)
+        D.apply(gd.weights_init_normal)
+        for n, p in G.named_parameters():
+            if n.endswith("gamma"):
+                p.data.fill_(0.1)                                     # attention active (reference init is 0)
+        if not args.no_perceptual:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                perc = gd.PerceptualLoss(pretrained=False, device=dev)
+        broadcast_module(G)
+        broadcast_module(D)
+        if perc is not None:
+            broadcast_module(perc)
+        G.train()
+        D.train()
+        trainer = gd.GanTrainer(G, D, perceptual=perc)
+        # synthetic shard, resident in HBM before the timed region
+        x = torch.randn(B, Cin, T, T, device=dev, generator=gen)
+        target = torch.randn(B, 1, 4 * T, 4 * T, device=dev, generator=gen)
+        last = {}
+
+        def step():
+            last["out"] = trainer.step(x, target, 0.5)
+            return last["out"].loss_g
+        workload = (f"full G+D train step, {Cin}ch {T}x{T} -> {4 * T}x{4 * T} tiles, batch {B}/GPU (global {B * world}), "
+                    f"perceptual={'on' if perc is not None else 'OFF'}, SSIM evaluated, AdamW x2")
+        metric = f"train samples/sec (G+D step) on {T}x{T} tiles"
 
     def sync():
         if world > 1:
@@ -143,13 +229,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(x, target, 0.5)
+        step()
     sync()
     kern.PROFILE.clear()
     kern.PROFILE_ON = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = trainer.step(x, target, 0.5)
+        res_t = step()
     sync()
     dt = time.perf_counter() - t0
     kern.PROFILE_ON = False
@@ -158,33 +244,46 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
-    loss_d, loss_g = out.loss_d.item(), out.loss_g.item()
-    finite = bool(torch.isfinite(out.loss_d).all() and torch.isfinite(out.loss_g).all())
+    finite = bool(torch.isfinite(res_t).all())
+    if cfg in (3, 4):
+        out = last["out"]
+        extra = {"loss_d": out.loss_d.item(), "loss_g": out.loss_g.item()}
+        finite = finite and bool(torch.isfinite(out.loss_d).all())
+    elif cfg == 5:
+        extra = {"loss": res_t.item()}
 
     # ---- roofline of the dominant kernel from the HIP-event brackets recorded around its launches ----
+    # `traffic` = HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE),
+    # measured by tools/run_profiles.sh at the commit named in the file, at exactly config 3's launch shape
     roof = None
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_pam_traffic.json")
-    if os.path.exists(tpath) and B == 32 and T == 256:   # PMC bytes measured offline at exactly this launch shape (C=184)
+    traffic, traffic_commit = {}, None
+    tpath = os.path.join(ROOT, "profiles", "r02_pam_traffic.json")
+    if os.path.exists(tpath) and cfg in (3, 4) and B == 32 and T == 256:
         with open(tpath) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch", {})
+            tj = json.load(f)
+        traffic, traffic_commit = tj.get("traffic_bytes_per_launch", {}), tj.get("commit")
     stats = kern.profile_summary()
     if stats:
         name, (n_launch, ms_avg, flops, nbytes) = max(stats.items(), key=lambda kv: kv[1][0] * kv[1][1])
         ach = flops / (ms_avg * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic.get(name),
+                "traffic_measured_at_commit": traffic_commit,
                 "launches": n_launch, "avg_ms": round(ms_avg, 3),
                 "algorithmic_flop_per_launch": flops,
                 "all": {k: {"launches": v[0], "avg_ms": round(v[1], 3),
                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in stats.items()}}
+        if "pam_flash_fwd" in stats and "pam_flash_bwd" in stats:      # the "256x256 PAM GEMM" utilisation (fwd + bwd)
+            tf = sum(stats[k][0] * stats[k][1] for k in ("pam_flash_fwd", "pam_flash_bwd")) * 1e-3
+            ff = sum(stats[k][0] * stats[k][2] for k in ("pam_flash_fwd", "pam_flash_bwd"))
+            roof["pam_fwd_bwd"] = {"tflops": round(ff / tf / 1e12, 1), "frac": round(ff / tf / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_baseline_steps)
         res = {
-            "metric": "train samples/sec (G+D step) on 256x256 tiles",
+            "metric": metric,
             "value": round(args.steps * B * world / dt, 3),
             "unit": "samples/s",
             "n_gpus": world,
@@ -195,13 +294,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.precision,
-            "data": "synthetic (randn tiles, random-init weights, random-init VGG19 for the perceptual term)",
-            "config": {"workload": f"full G+D train step, {Cin}ch {T}x{T} -> {4 * T}x{4 * T} tiles, batch {B}/GPU "
-                                   f"(global {B * world}), perceptual={'on' if perc is not None else 'OFF'}, "
-                                   f"SSIM evaluated, AdamW x2",
+            "data": "synthetic (randn tiles, random-init weights" + (", random-init VGG19 for the perceptual term)" if perc is not None else ")"),
+            "config": {"workload": workload, "survey_config": cfg,
                        "per_gpu_batch": B, "global_batch": B * world, "tile": T, "parallelism": f"dp{world}",
-                       "storage": "fp32 activations/weights, bf16 MFMA operands, fp32 accumulate"},
-            "loss_d": loss_d, "loss_g": loss_g, "finite": finite,
+                       "storage": "fp32 activations/weights, 16-bit MFMA operands (" + args.precision + "), fp32 accumulate"
+                                  if args.precision != "fp32" else "fp32 everywhere (exact f32 MFMA)"},
+            **extra, "finite": finite,
+            "g_out_rel_err": g_out_rel_err(gd, dev, args.precision),
             "roofline": roof,
             "cpu_baseline": cpu,
             "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

@@ -70,11 +70,12 @@ def pmc(d):
             if n == "WRITE_SIZE":
                 extra = f"   KiB = {c[n] * 1024 / 1e9:.2f} GB per dispatch"
             print(f"    {n:32s} {c[n]:14.4g}{extra}")
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-            # busy cycles are summed over the SEs' SQs: per-SIMD share = MFMA busy / (4 SIMDs x CU-busy); use wave cycles:
-            # waves are resident the whole kernel, so SIMD-cycles ~= 4 * SQ_WAVE_CYCLES / waves_per_SIMD ...
-            pass
-        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in c and "SQ_INSTS_VALU" in c:
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and wc:
+            # waves are resident for the whole kernel: SIMD-cycles = 4 (quad) * SQ_WAVE_CYCLES / (waves sharing a SIMD)
+            wps = 1 if "k64" in k else 2
+            print(f"    -> matrix pipe busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc / wps):.3f} of the SIMD-cycles "
+                  f"({wps} wave(s) per SIMD)")
+        if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0 and "SQ_INSTS_VALU" in c:
             mf = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / 64      # a 32x32x16 bf16 MFMA counts 64 MOPS units (512 flop each)
             print(f"    -> MFMA instructions {mf:.4g}; VALU instructions per MFMA {c['SQ_INSTS_VALU'] / mf - 1:.2f}")
         if "GRBM_GUI_ACTIVE" in c and ms > 0:
