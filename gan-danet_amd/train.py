@@ -43,7 +43,7 @@ class GanTrainer:
                  lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
                  compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
                  batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None,
-                 reduce_gradients: bool = True) -> None:
+                 reduce_gradients: bool = True, external_world: Optional[int] = None) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
         # optional gate on the combined input (the notebook's attention_module / senet_module, L145-171,
         # L229-232: SqueezeExcitation or CBAMBlock); its parameters join the generator's optimiser (L165-175)
@@ -51,7 +51,11 @@ class GanTrainer:
         g_params = list(G.parameters()) + (list(input_attention.parameters()) if input_attention is not None else [])
         # reduce_gradients=False: this process trains an INDEPENDENT replica (an ensemble member, checkpoint.py) even
         # when torch.distributed is initialised -- no gradient exchange, no 1/world scaling
+        # external_world = W: the caller sums this trainer's gradients with W - 1 other shards itself between
+        # d_backward / g_backward and the optimiser steps (no torch.distributed): same 1/W scale as W ranks
         ws = world_size() if reduce_gradients else 1
+        if external_world is not None:
+            reduce_gradients, ws = False, int(external_world)
         self._reduce = reduce_gradients
         self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
         self.opt_g = AdamW(g_params, lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
@@ -77,11 +81,25 @@ class GanTrainer:
         return self.step(K.combine_inputs(lr_grace_05, hr_aux, 0.5, 0.25), lr_grace_025, loss_weight)
 
     def step(self, x: torch.Tensor, target: torch.Tensor, loss_weight: float) -> StepOutput:
-        G, D = self.G, self.D
+        """one G+D update (L243-269) = d_backward -> reduce -> D.step -> g_backward -> reduce -> G.step.  The two
+        backward phases are separate methods so that an EXTERNAL exchange of gradients (tests emulating N ranks in
+        one process, other communication layers) can sit where ``GradReducer.reduce`` does."""
         if self._reduce and world_size() != self._world:
             raise RuntimeError(f"GanTrainer was built for world size {self._world} but torch.distributed now reports "
                                f"{world_size()}: construct the trainer AFTER init_process_group (its AdamW gradient "
                                "scale and all-reduce hooks are fixed at construction)")
+        st = self.d_backward(x, target)
+        self.red_d.reduce()
+        self.opt_d.step()
+        self.g_backward(st, target, loss_weight)
+        self.red_g.reduce()
+        self.opt_g.step()
+        return self.finish(st)
+
+    def d_backward(self, x: torch.Tensor, target: torch.Tensor) -> dict:
+        """generator forward (ONE per step, reused by both updates, L243) and the discriminator's loss + backward
+        (L246-255); gradients are left un-reduced in ``D.parameters()``"""
+        G, D = self.G, self.D
         hr = G(x if self.input_attention is None else self.input_attention(x))
 
         # ---- discriminator update (L246-256) ----
@@ -100,9 +118,12 @@ class GanTrainer:
             fake = D(hr.detach())
         loss_d = ops.weighted_sum([0.5, 0.5], [ops.bce_with_logits(real, 1.0), ops.bce_with_logits(fake, 0.0)])
         loss_d.backward()
-        self.red_d.reduce()
-        self.opt_d.step()
+        return {"hr": hr, "loss_d": loss_d.detach()}
 
+    def g_backward(self, st: dict, target: torch.Tensor, loss_weight: float) -> None:
+        """generator loss against the ALREADY UPDATED discriminator and its backward (L259-268); gradients are left
+        un-reduced in the generator's parameters"""
+        D, hr = self.D, st["hr"]
         # ---- generator update (L259-269) ----
         self.opt_g.zero_grad(set_to_none=True)
         d_flags = [p.requires_grad for p in D.parameters()]
@@ -125,12 +146,14 @@ class GanTrainer:
         finally:
             for p, f in zip(D.parameters(), d_flags):
                 p.requires_grad_(f)
-        self.red_g.reduce()
-        self.opt_g.step()
+        st.update(loss_g=loss_g.detach(), adv=adv.detach(), pix=pix.detach(), tv=tv.detach(),
+                  perc=None if perc is None else perc.detach(), ssim=ssim_term)
 
-        parts = {"adv": adv.detach(), "pix": pix.detach(), "tv": tv.detach()}
-        if perc is not None:
-            parts["perc"] = perc.detach()
-        if ssim_term is not None:
-            parts["ssim"] = ssim_term   # SSIM value; the reference logs 1 - SSIM and never uses it
-        return StepOutput(loss_d.detach(), loss_g.detach(), parts, hr.detach())
+    @staticmethod
+    def finish(st: dict) -> StepOutput:
+        parts = {"adv": st["adv"], "pix": st["pix"], "tv": st["tv"]}
+        if st["perc"] is not None:
+            parts["perc"] = st["perc"]
+        if st["ssim"] is not None:
+            parts["ssim"] = st["ssim"]   # SSIM value; the reference logs 1 - SSIM and never uses it
+        return StepOutput(st["loss_d"], st["loss_g"], parts, st["hr"].detach())

@@ -1,0 +1,107 @@
+"""GPU, 2 processes: the data-parallel G+D step through ``GanTrainer`` on the real HIP modules.
+
+Two FRESH child interpreters (tests/ddp_worker.py; gloo, both ranks on cuda:0 -- the box has one GPU) each run
+``GanTrainer.step`` on their half of a 4-sample batch.  Checked:
+  (a) the result equals a single-process emulation of two ranks -- two trainers on the two shards whose gradients are
+      summed by hand between ``d_backward`` / ``g_backward`` and the optimiser steps (per-shard BatchNorm statistics and
+      per-shard TV loss, i.e. DDP semantics);
+  (b) the replicas are BIT-IDENTICAL after the steps (same summed gradients, same AdamW arithmetic);
+  (c) BN running statistics stay per-replica (they differ between ranks: each saw its own shard).
+No scaling is measured here: SCALE_rNN.json is the driver's."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from fill import fill_module, seeded
+from gpu_util import DEV, rell2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _emulate_two_ranks(steps):
+    import gan_danet_amd as gd
+    gb = 4
+    x, tgt = seeded((gb, 8, 16, 16), 21).to(DEV), seeded((gb, 1, 64, 64), 22).to(DEV)
+    trs = []
+    with gd.precision("fp32"):
+        for r in range(2):
+            G = gd.FlexibleUpsamplingModule(input_channels=8).to(DEV)
+            D = gd.Discriminator1().to(DEV)
+            with torch.no_grad():
+                D(tgt[:1])
+            fill_module(G), fill_module(D)
+            G.train(), D.train()
+            trs.append(gd.GanTrainer(G, D, perceptual=None, external_world=2))
+
+        def exchange(params_a, params_b):
+            for pa, pb in zip(params_a, params_b):
+                if pa.grad is None:
+                    continue
+                s = pa.grad + pb.grad              # the all-reduce SUM (plumbing of the emulation)
+                pa.grad.copy_(s), pb.grad.copy_(s)
+
+        for _ in range(steps):
+            sts = [t.d_backward(x[2 * r:2 * r + 2], tgt[2 * r:2 * r + 2]) for r, t in enumerate(trs)]
+            exchange(list(trs[0].D.parameters()), list(trs[1].D.parameters()))
+            for t in trs:
+                t.opt_d.step()
+            for r, t in enumerate(trs):
+                t.g_backward(sts[r], tgt[2 * r:2 * r + 2], 0.5)
+            exchange(list(trs[0].G.parameters()), list(trs[1].G.parameters()))
+            for t in trs:
+                t.opt_g.step()
+    torch.cuda.synchronize()
+    return trs, [s["loss_g"].item() for s in sts]
+
+
+def test_two_rank_ganstep_matches_emulation_and_replicas_stay_identical(tmp_path):
+    steps, port = 2, _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_PREC="fp32")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", str(port),
+                               str(tmp_path), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    # (b) replicas bit-identical in every PARAMETER; (c) BN running statistics are per replica
+    bn_keys = [k for k in r0["G"] if k.endswith("running_mean") or k.endswith("running_var")]
+    for net in ("G", "D"):
+        for k in r0[net]:
+            if k in bn_keys or k.endswith("num_batches_tracked"):
+                continue
+            assert torch.equal(r0[net][k], r1[net][k]), f"replicas differ in {net}.{k}"
+    assert any(not torch.equal(r0["G"][k], r1["G"][k]) for k in bn_keys), "BN statistics should be per-replica (DDP semantics)"
+    # (a) against the single-process two-shard emulation
+    trs, _ = _emulate_two_ranks(steps)
+    for net, mod in (("G", trs[0].G), ("D", trs[0].D)):
+        for k, v in mod.state_dict().items():
+            if k.endswith("num_batches_tracked") or k.endswith("key.bias"):
+                continue       # key.bias: analytically ZERO gradient (softmax shift invariance) -> pure round-off,
+                               # which AdamW's sign-like first steps turn into +-lr moves in either run
+            e = rell2(v, r0[net][k]) if v.dtype.is_floating_point else float(not torch.equal(v.cpu(), r0[net][k]))
+            # AdamW's early steps are sign-like: elements whose gradient sits at fp32 round-off level (the order in
+            # which atomics / gloo sum differs between the two runs) may move by +-lr either way
+            assert e <= 2e-3, f"{net}.{k}: 2-process vs emulation rel err {e:.2e}"
+    # rank 1's BN statistics equal the emulation's second trainer
+    for k in bn_keys:
+        assert rell2(trs[1].G.state_dict()[k], r1["G"][k]) <= 1e-5, k
