@@ -81,6 +81,9 @@ class EarlyStopping:
 
 
 def save_training_state(path: str, trainer, epoch: int, schedulers: Sequence = (), extra: Optional[Dict] = None) -> None:
+    """collective under data parallelism (the optimiser state of sharded tensors is gathered): call on every rank"""
+    if hasattr(trainer, "sync_params"):
+        trainer.sync_params()
     state = {
         "epoch": int(epoch),
         "G": trainer.G.state_dict(),

@@ -11,6 +11,14 @@ small gradients are packed into flat buckets of ``bucket_bytes`` and big tensors
 are reduced in place.  A big tensor's all-reduce is launched THE MOMENT autograd has finished its gradient
 (post-accumulate hook): fc1 sits at the end of the discriminator, so its 8.6 GB gradient is ready first and
 travels under the backward of the four conv layers; everything is waited on together in ``reduce()``.
+
+``ShardedParam`` (ZeRO-1 for the one tensor that matters): Discriminator1.fc1 is 2.1e9 parameters at 256x256 tiles --
+all-reducing its gradient moves 8.6 GB per rank per step and every rank then streams the same 34 GB of AdamW state.
+Sharded, a rank receives only ITS 1/world slice of the summed gradient (reduce-scatter, launched from the same
+gradient hook), updates that slice with 1/world of the optimiser state and traffic, and the updated slices are
+all-gathered back into the full weight, waited for by a forward pre-hook of the discriminator (the gather runs under
+whatever the step does between the D update and the next D forward).  Replicas stay identical: the arithmetic per
+element is unchanged.
 """
 from __future__ import annotations
 
@@ -52,10 +60,98 @@ def shard_batch(global_batch: int, world: Optional[int] = None, rk: Optional[int
     return slice(lo, lo + base + (1 if rk < rem else 0))
 
 
-class GradReducer:
-    """Sum-all-reduce of a parameter list's ``.grad`` tensors with bucketing of the small ones."""
+def _backend_has_reduce_scatter(group=None) -> bool:
+    return dist.get_backend(group) != "gloo"       # gloo: no reduce_scatter / all_gather_into_tensor on all builds
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None) -> None:
+
+class ShardedParam:
+    """One big parameter whose gradient sum, optimiser state and update are split 1/world per rank (module docstring).
+    ``numel`` must be a multiple of the world size (Discriminator1.fc1: 1024 x 32 H W)."""
+
+    def __init__(self, p: torch.nn.Parameter, group=None) -> None:
+        self.p, self.group = p, group
+        self.world, self.rank = world_size(), rank()
+        if p.numel() % self.world:
+            raise ValueError(f"ShardedParam: {p.numel()} elements do not split over {self.world} ranks")
+        self.n = p.numel() // self.world
+        self.lo = self.rank * self.n
+        self.gshard: Optional[torch.Tensor] = None
+        self._rs: list = []
+        self._ag: list = []
+        self._tmp = None
+
+    # ---- gradient: reduce-scatter (launched from the post-accumulate hook) ----
+    def launch_reduce_scatter(self) -> None:
+        g = self.p.grad.reshape(-1)
+        if _backend_has_reduce_scatter(self.group):
+            if self.gshard is None:
+                self.gshard = torch.empty(self.n, device=g.device, dtype=g.dtype)
+            self._rs = [dist.reduce_scatter_tensor(self.gshard, g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        else:       # gloo (CPU tests / one-GPU rehearsal): one reduce per destination rank, in place on the gradient
+            self._rs = [dist.reduce(g[r * self.n:(r + 1) * self.n], dst=r, op=dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True) for r in range(self.world)]
+            self.gshard = g[self.lo:self.lo + self.n]
+
+    def wait_grad(self) -> torch.Tensor:
+        for w in self._rs:
+            w.wait()
+        self._rs = []
+        return self.gshard
+
+    def param_shard(self) -> torch.Tensor:
+        return self.p.data.view(-1)[self.lo:self.lo + self.n]
+
+    # ---- parameter: all-gather of the updated slices (waited for by the owning layer's forward pre-hook) ----
+    @torch.no_grad()
+    def launch_all_gather(self) -> None:
+        full = self.p.data.view(-1)
+        self._tmp = self.param_shard().clone()          # send buffer (1/world of the tensor)
+        if _backend_has_reduce_scatter(self.group):
+            self._ag = [dist.all_gather_into_tensor(full, self._tmp, group=self.group, async_op=True)]
+        else:
+            self._ag = [dist.all_gather([full[r * self.n:(r + 1) * self.n] for r in range(self.world)], self._tmp,
+                                        group=self.group, async_op=True)]
+
+    def wait_param(self) -> None:
+        for w in self._ag:
+            w.wait()
+        self._ag, self._tmp = [], None
+
+    # ---- optimiser state of the whole tensor <-> this rank's slice (checkpoints hold FULL tensors) ----
+    @torch.no_grad()
+    def gather_state(self, shard: torch.Tensor) -> torch.Tensor:
+        full = torch.empty(self.n * self.world, device=shard.device, dtype=shard.dtype)
+        dist.all_gather([full[r * self.n:(r + 1) * self.n] for r in range(self.world)], shard.contiguous(), group=self.group)
+        return full.view_as(self.p)
+
+    def slice_state(self, full: torch.Tensor) -> torch.Tensor:
+        return full.reshape(-1)[self.lo:self.lo + self.n].clone()
+
+
+def shard_big_params(module: torch.nn.Module, min_bytes: int, group=None) -> List[ShardedParam]:
+    """ShardedParam for every parameter of ``module`` with at least ``min_bytes`` whose size splits over the ranks.
+    A forward pre-hook on ``module`` ITSELF waits for the all-gathers of the updated weights: correct for any forward
+    (a hook on the owning sub-module would let the gather run under the layers in front of it, but a forward that reads
+    ``sub.weight`` functionally never fires it and would silently compute with stale slices)."""
+    out: List[ShardedParam] = []
+    if not is_distributed():
+        return out
+    for p in module.parameters():
+        if isinstance(p, torch.nn.parameter.UninitializedParameter):
+            continue
+        if p.numel() * p.element_size() >= min_bytes and p.numel() % world_size() == 0:
+            out.append(ShardedParam(p, group))
+    if out:
+        module.register_forward_pre_hook(lambda mod, args, sps=tuple(out): [sp.wait_param() for sp in sps] and None)
+    return out
+
+
+class GradReducer:
+    """Sum-all-reduce of a parameter list's ``.grad`` tensors with bucketing of the small ones; parameters given as
+    ``sharded`` get a reduce-scatter instead (their owner only receives its slice of the sum)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
+                 sharded: Iterable[ShardedParam] = ()) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params]
         self.bucket_bytes = bucket_bytes
         self.group = group
@@ -63,11 +159,15 @@ class GradReducer:
         self._early = {}            # id(param) -> Work of an all-reduce already in flight for this backward
         self._hooks = []
         self._world = world_size()      # hooks are registered (or not) for THIS world: reduce() checks it still holds
+        self._sharded = {id(sp.p): sp for sp in sharded}
+        self._rs_launched = set()
         if is_distributed():
             for p in self.params:
                 if isinstance(p, torch.nn.parameter.UninitializedParameter):
                     continue
-                if p.numel() * p.element_size() >= self.bucket_bytes and hasattr(p, "register_post_accumulate_grad_hook"):
+                if id(p) in self._sharded:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._launch_rs))
+                elif p.numel() * p.element_size() >= self.bucket_bytes and hasattr(p, "register_post_accumulate_grad_hook"):
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._launch_early))
 
     def close(self) -> None:
@@ -81,6 +181,11 @@ class GradReducer:
         if p.grad is not None and id(p) not in self._early:
             self._early[id(p)] = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _launch_rs(self, p: torch.nn.Parameter) -> None:
+        if p.grad is not None and id(p) not in self._rs_launched:
+            self._sharded[id(p)].launch_reduce_scatter()
+            self._rs_launched.add(id(p))
+
     @torch.no_grad()
     def reduce(self) -> None:
         if world_size() != self._world:
@@ -90,7 +195,14 @@ class GradReducer:
             return
         early_ids = set(self._early.keys())           # big tensors whose all-reduce started during the backward
         works = [self._early.pop(i) for i in early_ids]
-        grads = [p.grad for p in self.params if p.grad is not None and id(p) not in early_ids]
+        for p in self.params:                         # sharded tensors: reduce-scatter (from the hook, or here)
+            if id(p) in self._sharded and p.grad is not None:
+                if id(p) not in self._rs_launched:
+                    self._sharded[id(p)].launch_reduce_scatter()
+                self._sharded[id(p)].wait_grad()
+        self._rs_launched.clear()
+        grads = [p.grad for p in self.params
+                 if p.grad is not None and id(p) not in early_ids and id(p) not in self._sharded]
         buckets = []
         cur, cur_bytes = [], 0
         for g in grads:

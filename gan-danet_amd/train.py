@@ -22,7 +22,7 @@ from torch import nn
 from . import kern as K
 from . import ops
 from .optim import AdamW
-from .parallel import GradReducer, world_size
+from .parallel import GradReducer, shard_big_params, world_size
 
 
 @dataclass
@@ -43,7 +43,8 @@ class GanTrainer:
                  lr_d: float = 4e-4, betas=(0.5, 0.999), weight_decay: float = 1e-4, tv_weight: float = 1e-5,
                  compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
                  batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None,
-                 reduce_gradients: bool = True, external_world: Optional[int] = None) -> None:
+                 reduce_gradients: bool = True, external_world: Optional[int] = None,
+                 shard_bytes: int = 256 << 20) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
         # optional gate on the combined input (the notebook's attention_module / senet_module, L145-171,
         # L229-232: SqueezeExcitation or CBAMBlock); its parameters join the generator's optimiser (L165-175)
@@ -57,9 +58,13 @@ class GanTrainer:
         if external_world is not None:
             reduce_gradients, ws = False, int(external_world)
         self._reduce = reduce_gradients
-        self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
+        # discriminator tensors of >= shard_bytes (Discriminator1.fc1: 8.6 GB at 256x256 tiles) take the
+        # reduce-scatter -> 1/world AdamW -> all-gather route under data parallelism (parallel.ShardedParam)
+        self.sharded = shard_big_params(D, shard_bytes) if (reduce_gradients and shard_bytes > 0) else []
+        self.opt_d = AdamW(D.parameters(), lr=lr_d, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws,
+                           sharded=self.sharded)
         self.opt_g = AdamW(g_params, lr=lr_g, betas=betas, weight_decay=weight_decay, grad_scale=1.0 / ws)
-        self.red_d = GradReducer(D.parameters()) if reduce_gradients else _NoReduce()
+        self.red_d = GradReducer(D.parameters(), sharded=self.sharded) if reduce_gradients else _NoReduce()
         self.red_g = GradReducer(g_params) if reduce_gradients else _NoReduce()
         # TVLoss divides by the batch size twice (losses.py:82-87): per-shard TV averaged over ranks is `world`
         # times the single-device global-batch value.  Default = plain DDP semantics (per-shard loss, as the
@@ -95,6 +100,12 @@ class GanTrainer:
         self.red_g.reduce()
         self.opt_g.step()
         return self.finish(st)
+
+    def sync_params(self) -> None:
+        """wait for the all-gathers of sharded weights still in flight (before reading D's parameters outside a
+        forward: checkpoints, tests)"""
+        for sp in self.sharded:
+            sp.wait_param()
 
     def d_backward(self, x: torch.Tensor, target: torch.Tensor) -> dict:
         """generator forward (ONE per step, reused by both updates, L243) and the discriminator's loss + backward

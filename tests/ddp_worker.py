@@ -21,6 +21,7 @@ from fill import fill_module, seeded  # noqa: E402
 from gan_danet_amd.parallel import broadcast_module, shard_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
+gd.set_deterministic(os.environ.get("DDP_DETERMINISTIC", "0") == "1")     # bitwise run-to-run comparisons
 gb = 4
 x, tgt = seeded((gb, 8, 16, 16), 21).to(dev), seeded((gb, 1, 64, 64), 22).to(dev)
 torch.manual_seed(100 + rank)                        # replicas start DIFFERENT on purpose: broadcast must fix it
@@ -36,10 +37,21 @@ with gd.precision(prec):
     broadcast_module(G)
     broadcast_module(D)
     G.train(), D.train()
-    tr = gd.GanTrainer(G, D, perceptual=None)        # built AFTER init_process_group: world = 2
+    shard_bytes = int(os.environ.get("DDP_SHARD_BYTES", "0"))
+    tr = gd.GanTrainer(G, D, perceptual=None, shard_bytes=shard_bytes)   # built AFTER init_process_group: world = 2
+    if shard_bytes:
+        assert any(sp.p is D.fc1.weight for sp in tr.sharded), "fc1 should take the reduce-scatter / sharded-AdamW path"
     sl = shard_batch(gb, world, rank)
     outs = [tr.step(x[sl], tgt[sl], 0.5) for _ in range(steps)]
+tr.sync_params()
 torch.cuda.synchronize()
+if os.environ.get("DDP_SHARD_BYTES"):
+    # the optimiser state of a sharded tensor is 1/world of it on each rank; state_dict() returns the full tensors
+    st = tr.opt_d.state[D.fc1.weight]
+    assert st["exp_avg"].numel() == D.fc1.weight.numel() // world
+    full = tr.opt_d.state_dict()
+    idx = [i for i, p in enumerate(D.parameters()) if p is D.fc1.weight][0]
+    assert full["state"][idx]["exp_avg"].shape == D.fc1.weight.shape
 state = {"G": {k: v.detach().cpu() for k, v in G.state_dict().items()},
          "D": {k: v.detach().cpu() for k, v in D.state_dict().items()},
          "loss_d": [o.loss_d.item() for o in outs], "loss_g": [o.loss_g.item() for o in outs]}

@@ -110,3 +110,77 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _worker_sharded(rank, world, port, tmpdir):
+    """reduce-scatter -> 1/world AdamW -> all-gather (parallel.ShardedParam + optim.AdamW(sharded=...)) against the
+    all-reduce + full AdamW path, with the ORACLE's AdamW arithmetic injected as the update function (the HIP kernel
+    needs a GPU; what is under test is the host-side sharding logic)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from fill import seeded
+    from gan_danet_amd.optim import AdamW
+    from gan_danet_amd.parallel import GradReducer, broadcast_module, shard_batch, shard_big_params
+    from oracle import functional as OF
+    from oracle import modules as OM
+
+    def upd(p, g, m, v, step, lr, b1, b2, eps, wd, gscale):
+        OF.adamw_update(p, g * gscale, m, v, step, lr, b1, b2, eps, wd)
+
+    gb = 4
+    tgt = seeded((gb, 1, 32, 32), 5)
+    sl = shard_batch(gb, world, rank)
+    results = []
+    for sharded_mode in (False, True):
+        torch.manual_seed(7)
+        D = OM.Discriminator1()
+        with torch.no_grad():
+            D(tgt[:1])
+        broadcast_module(D, src=0)
+        sps = shard_big_params(D, 1 << 20) if sharded_mode else []      # fc1 (8 MiB), conv4 (4.5 MiB), conv3 (1.1 MiB)
+        if sharded_mode:
+            assert len(sps) == 3 and any(sp.p is D.fc1.weight for sp in sps)
+        red = GradReducer(D.parameters(), bucket_bytes=64 << 10, sharded=sps)
+        opt = AdamW(D.parameters(), lr=4e-4, betas=(0.5, 0.999), weight_decay=1e-4, grad_scale=1.0 / world, sharded=sps,
+                    update_fn=upd)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            o = D(tgt[sl])                       # the fc1 forward pre-hook waits for the previous all-gather
+            OF.bce_with_logits(o, torch.ones_like(o)).backward()
+            red.reduce()
+            opt.step()
+        for sp in sps:
+            sp.wait_param()
+        if sharded_mode:
+            st = opt.state[D.fc1.weight]
+            assert st["exp_avg"].numel() == D.fc1.weight.numel() // world       # 1/world of the state per rank
+        sd = opt.state_dict()                    # collective: full tensors whatever the sharding
+        idx = [i for i, p in enumerate(D.parameters()) if p is D.fc1.weight][0]
+        assert sd["state"][idx]["exp_avg"].shape == D.fc1.weight.shape
+        results.append(([p.detach().clone() for p in D.parameters()], sd["state"][idx]["exp_avg"].clone(),
+                        sd["state"][idx]["exp_avg_sq"].clone()))
+        if sharded_mode:                         # round trip: load the full state back, slices must match
+            before = opt.state[D.fc1.weight]["exp_avg"].clone()
+            opt.load_state_dict(sd)
+            assert torch.equal(opt.state[D.fc1.weight]["exp_avg"], before)
+        red.close()
+    for (nm, _), a, b in zip(D.named_parameters(), results[0][0], results[1][0]):
+        assert torch.equal(a, b), f"sharded optimiser path changed {nm}: max diff {(a - b).abs().max().item():.3e}"
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    w = results[1][0][-1]
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    assert torch.equal(gathered[0], gathered[1]), "replicas diverged"
+    open(os.path.join(tmpdir, f"sh_ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_two_ranks_gloo(tmp_path):
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_sharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"sh_ok{r}").exists() for r in range(world))

@@ -65,11 +65,12 @@ def _emulate_two_ranks(steps):
     return trs, [s["loss_g"].item() for s in sts]
 
 
-def test_two_rank_ganstep_matches_emulation_and_replicas_stay_identical(tmp_path):
-    steps, port = 2, _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_PREC="fp32")
+def _run_two_ranks(outdir, steps, **extra_env):
+    os.makedirs(outdir, exist_ok=True)
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_PREC="fp32", **extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", str(port),
-                               str(tmp_path), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(outdir), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     logs = []
     for p in procs:
@@ -81,8 +82,21 @@ def test_two_rank_ganstep_matches_emulation_and_replicas_stay_identical(tmp_path
             raise
         logs.append(out.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
-    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    return (torch.load(os.path.join(outdir, "rank0.pt"), weights_only=True),
+            torch.load(os.path.join(outdir, "rank1.pt"), weights_only=True))
+
+
+def test_two_rank_ganstep_matches_emulation_and_replicas_stay_identical(tmp_path):
+    steps = 2
+    # deterministic mode (no atomic split reductions): two separate runs can then be compared bit for bit
+    r0, r1 = _run_two_ranks(str(tmp_path / "plain"), steps, DDP_DETERMINISTIC="1")
+    # fc1 (and every other tensor >= 1 MiB) through reduce-scatter -> sharded AdamW -> all-gather: the same arithmetic
+    # per element, so the result must not change by a single bit
+    s0, s1 = _run_two_ranks(str(tmp_path / "sharded"), steps, DDP_DETERMINISTIC="1", DDP_SHARD_BYTES=str(1 << 20))
+    for net in ("G", "D"):
+        for k in r0[net]:
+            assert torch.equal(r0[net][k], s0[net][k]), f"sharded optimiser path changed {net}.{k}"
+            assert torch.equal(r1[net][k], s1[net][k]), f"sharded optimiser path changed {net}.{k} (rank 1)"
     # (b) replicas bit-identical in every PARAMETER; (c) BN running statistics are per replica
     bn_keys = [k for k in r0["G"] if k.endswith("running_mean") or k.endswith("running_var")]
     for net in ("G", "D"):
