@@ -120,6 +120,13 @@ SIGNATURES = {
     "gd_row_dot": (_i, [_p, _p, _p, _l, _l, _p]),
     "gd_chan_maxmean_fwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
     "gd_chan_maxmean_bwd": (_i, [_p, _p, _p, _i, _i, _l, _p]),
+    "gd_comm_unique_id": (_i, [C.c_char_p]),
+    "gd_comm_init": (_i, [_i, _i, C.c_char_p]),
+    "gd_comm_world": (_i, []),
+    "gd_allreduce": (_i, [_p, _sz, _i, _p]),
+    "gd_reduce_scatter": (_i, [_p, _p, _sz, _i, _p]),
+    "gd_allgather": (_i, [_p, _p, _sz, _i, _p]),
+    "gd_comm_destroy": (_i, []),
     "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "gd_pack_16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
 }

@@ -346,6 +346,25 @@ int gd_pack_16(const float* s, long s_bs, int B, int R, int Cc, const float* sca
                int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, int ones_row, int f16,
                void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RCCL communicator for hosts without torch.distributed (one process per GPU, one communicator per process; the
+ * Python package here goes through torch.distributed's "nccl" backend, which IS RCCL, and does not call these).
+ * librccl is dlopen()ed on first use (GD_RCCL_PATH overrides the search).  dtype: 0 fp32, 1 bf16, 2 fp16.  All
+ * collectives are in-place-capable, sum-reducing, asynchronous on `stream`.
+ *   gd_comm_unique_id : rank 0 creates the 128-byte id; the host distributes it (env, file, TCP store)
+ *   gd_comm_init      : collective over `world` processes
+ *   gd_allreduce      : buf (n elements) <- sum over ranks                     (gradient all-reduce, the G/D grads)
+ *   gd_reduce_scatter : recv (recv_n) <- this rank's slice of the sum of send (world * recv_n)     (fc1 gradient)
+ *   gd_allgather      : recv (world * send_n) <- every rank's send (send_n)                 (updated fc1 slices)
+ * ---------------------------------------------------------------------------------------- */
+int gd_comm_unique_id(char* id128);
+int gd_comm_init(int rank, int world, const char* id128);
+int gd_comm_world(void);
+int gd_allreduce(void* buf, size_t n, int dtype, void* stream);
+int gd_reduce_scatter(const void* send, void* recv, size_t recv_n, int dtype, void* stream);
+int gd_allgather(const void* send, void* recv, size_t send_n, int dtype, void* stream);
+int gd_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -545,3 +545,33 @@ def test_deterministic_mode_makes_split_reductions_reproducible(gd):
     assert torch.equal(d1[0], d2[0]) and torch.equal(d1[1], d2[1])
     assert_close(d1[0], base[0].cpu(), 1e-5, "deterministic vs default wgrad", rell2)
     assert_close(d1[1], base[1].cpu(), 1e-5, "deterministic vs default split-K", rell2)
+
+
+def test_rccl_comm_c_abi_single_rank(gd):
+    """gd_comm_* / gd_allreduce exist and drive RCCL (dlopen'ed) -- exercised with a world of one on the
+    box's single GPU: sum all-reduce, reduce-scatter and all-gather are identities; a second init is refused"""
+    import ctypes
+    from gan_danet_amd import _lib as L
+    lib = L.load()
+    ident = ctypes.create_string_buffer(128)
+    L.check(lib.gd_comm_unique_id(ident), "gd_comm_unique_id")
+    L.check(lib.gd_comm_init(0, 1, ident), "gd_comm_init")
+    try:
+        assert lib.gd_comm_world() == 1
+        assert lib.gd_comm_init(0, 1, ident) != 0 and "already" in L.last_error()
+        x = torch.arange(1000, device=DEV, dtype=torch.float32)
+        s = torch.cuda.current_stream().cuda_stream
+        L.check(lib.gd_allreduce(x.data_ptr(), x.numel(), 0, s), "gd_allreduce")
+        y = torch.empty_like(x)
+        L.check(lib.gd_reduce_scatter(x.data_ptr(), y.data_ptr(), x.numel(), 0, s), "gd_reduce_scatter")
+        z = torch.empty_like(x)
+        L.check(lib.gd_allgather(y.data_ptr(), z.data_ptr(), y.numel(), 0, s), "gd_allgather")
+        torch.cuda.synchronize()
+        ref = torch.arange(1000, dtype=torch.float32)
+        assert torch.equal(x.cpu(), ref) and torch.equal(y.cpu(), ref) and torch.equal(z.cpu(), ref)
+        h = torch.ones(64, device=DEV, dtype=torch.bfloat16)
+        L.check(lib.gd_allreduce(h.data_ptr(), h.numel(), 1, s), "gd_allreduce bf16")
+        assert lib.gd_allreduce(h.data_ptr(), h.numel(), 7, s) != 0
+    finally:
+        L.check(lib.gd_comm_destroy(), "gd_comm_destroy")
+    assert lib.gd_comm_world() == 0
