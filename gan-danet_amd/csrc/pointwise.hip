@@ -492,6 +492,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     if (threadIdx.x == 0) out[blockIdx.x] = (float)((redd[0] + redd[1] + redd[2] + redd[3]) * (double)scale);
 }
 
+// ---- inference post-processing (test.ipynb c1:87-101 smooth_blend) ------------------------------------------------
+// gen[b][c][sr + y][sc + x] = gen * (1 - mask[y][x]) + grace * mask[y][x] over the region, in place
+__global__ void blend_region_kernel(float* __restrict__ gen, const float* __restrict__ grace, const float* __restrict__ mask,
+                                    int H, int W, int sr, int sc, int rh, int rw, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long plane = i / ((long)rh * rw);
+        const int rem = (int)(i - plane * (long)rh * rw);
+        const int y = rem / rw, x = rem - y * rw;
+        const long o = plane * (long)H * W + (long)(sr + y) * W + (sc + x);
+        const float m = mask[rem];
+        gen[o] = gen[o] * (1.f - m) + grace[o] * m;
+    }
+}
+
 // ---- AdamW -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
@@ -770,6 +784,16 @@ extern "C" int gd_ssim_bwd(const float* a, const float* b, const float* gscale, 
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(ssim_bwd_coef_kernel, dim3(gx, B * C), dim3(256), 0, GD_S, a, b, C, H, W, win, gscale, coef_ws);
     hipLaunchKernelGGL(ssim_bwd_filter_kernel, dim3(gx, B * C), dim3(256), 0, GD_S, a, b, H, W, win, coef_ws, da, db);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_blend_region(float* gen, const float* grace, const float* mask, int BC, int H, int W, int sr, int er,
+                               int sc, int ec, void* stream) {
+    GD_CHECK_ARG(gen && grace && mask && BC > 0 && H > 0 && W > 0, "gd_blend_region: bad arguments");
+    GD_CHECK_ARG(0 <= sr && sr < er && er <= H && 0 <= sc && sc < ec && ec <= W, "gd_blend_region: region outside the image");
+    const long total = (long)BC * (er - sr) * (ec - sc);
+    hipLaunchKernelGGL(blend_region_kernel, dim3(grid_for(total)), dim3(256), 0, GD_S, gen, grace, mask, H, W, sr, sc, er - sr,
+                       ec - sc, total);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -342,6 +342,18 @@ def combine_inputs(lr: Tensor, aux: Tensor, s1: float = 0.5, s2: float = 0.25) -
     return out
 
 
+def blend_region(gen: Tensor, grace: Tensor, mask: Tensor, region) -> Tensor:
+    """in place on ``gen``: gen[.., sr:er, sc:ec] = gen * (1 - mask) + grace * mask"""
+    _dense(gen, "blend target"), _dense(grace, "blend source"), _dense(mask, "blend mask")
+    sr, er, sc, ec = (int(v) for v in region)
+    if gen.shape != grace.shape or tuple(mask.shape) != (er - sr, ec - sc):
+        raise L.GandanetError(f"blend_region: shapes {tuple(gen.shape)} / {tuple(grace.shape)} / mask {tuple(mask.shape)}")
+    B, Cn, H, W = gen.shape
+    L.check(lib().gd_blend_region(_ptr(gen), _ptr(grace), _ptr(mask), B * Cn, H, W, sr, er, sc, ec, _stream()),
+            "gd_blend_region")
+    return gen
+
+
 def bicubic_bwd(dy: Tensor, Hi: int, Wi: int, rsh: float, rsw: float) -> Tensor:
     _dense(dy, "bicubic dy")
     B, Cn, Ho, Wo = dy.shape

@@ -312,6 +312,10 @@ int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void*
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
                      float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream);
 
+/* test.ipynb c1:87-101 smooth_blend: over the region rows [sr, er) x columns [sc, ec) of every (b, c) plane,
+ * gen = gen * (1 - mask) + grace * mask, in place; mask (er-sr, ec-sc) fp32 is the feathered window the host builds. */
+int gd_blend_region(float* gen, const float* grace, const float* mask, int BC, int H, int W, int sr, int er, int sc,
+                    int ec, void* stream);
 /* CustomDataset.apply_augmentation (datasets.py:181-208) for a batch of tiles as one gather: per-sample op word
  * ops[b] = hflip | vflip << 1 | quarter_turns << 2 | noise << 4 (flip W, flip H, torch.rot90 k, in that order; H == W
  * when a sample is turned an odd number of times -- checked by the host).  noise (same shape as dst) may be NULL;

@@ -1,9 +1,10 @@
 """CPU restatement of ``CustomDataset`` (datasets.py:156-208) and of the notebook's un-shuffled ``DataLoader``
 batching (GAN_DANet_train.ipynb:L130-134).  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-``datasets.py`` itself cannot be imported here (h5py / netCDF4 / cv2 are absent), so this class is pinned by
-reading, not by running the reference: it uses the same torch calls in the same order, including the order of
-the ``random`` and ``torch.randn_like`` draws.
+Pinned against the reference itself: ``tests/golden/customdataset_6x8x8.npz`` holds what ``datasets.CustomDataset`` and
+``DataLoader`` returned in the build container (``tests/golden/make_golden_data.py``: ``datasets.py`` loaded by path with
+stand-ins for its two unused, absent imports), for plain items, batches, and twelve augmented items drawn from seeded
+``random`` / ``torch`` streams; ``tests/test_oracle_golden.py`` checks this class against it bit for bit.
 """
 from __future__ import annotations
 

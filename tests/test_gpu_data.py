@@ -1,6 +1,7 @@
 """f2: device-resident dataset + augmentation kernel against the CPU restatement of
 CustomDataset / DataLoader (oracle/data.py).  Geometry is a pure gather and the noise uses the same CPU torch
 stream in "reference" mode, so everything is bit-exact."""
+import os
 import random
 
 import numpy as np
@@ -99,3 +100,29 @@ def test_loader_batch_feeds_the_trainer_step():
     for lr05, lr025, aux in ds.batches(2):
         out = tr.step_from_batch(lr05, lr025, aux, 0.5)
         assert torch.isfinite(out.loss_d).all() and torch.isfinite(out.loss_g).all()
+
+
+def test_device_dataset_vs_reference_fixture(golden_dir):
+    """f2 pin on the PRODUCT path: DeviceTileDataset (gd_augment_d4 gather + reference-stream noise) against what the
+    reference's CustomDataset returned for the same seeds (tests/golden/customdataset_6x8x8.npz) -- bit for bit:
+    plain items, un-shuffled batches, and twelve augmented items in the reference's order of random draws"""
+    import random
+    from gan_danet_amd.data import DeviceTileDataset
+    fx = np.load(os.path.join(golden_dir, "customdataset_6x8x8.npz"))
+    ds = DeviceTileDataset(fx["lr_grace_05"], fx["lr_grace_025"], fx["hr_aux"], augment=False, device=DEV)
+    assert len(ds) == int(fx["length"])
+    a, b, c = ds[2]
+    assert np.array_equal(a.cpu().numpy(), fx["plain_a"]) and np.array_equal(c.cpu().numpy(), fx["plain_c"])
+    for i, (ba, bb, bc) in enumerate(ds.batches(4, rank=0, world=1)):
+        assert np.array_equal(ba.cpu().numpy(), fx[f"batch{i}_a"]) and np.array_equal(bb.cpu().numpy(), fx[f"batch{i}_b"])
+        assert np.array_equal(bc.cpu().numpy(), fx[f"batch{i}_c"])
+    dsa = DeviceTileDataset(fx["lr_grace_05"], fx["lr_grace_025"], fx["hr_aux"], augment=True, device=DEV, noise="reference")
+    random.seed(int(fx["seed_random"]))
+    torch.manual_seed(int(fx["seed_torch"]))
+    for rep in range(2):
+        for i in range(len(dsa)):
+            a, b, c = dsa[i]
+            k = f"aug{rep}_{i}"
+            assert np.array_equal(a.cpu().numpy(), fx[k + "_a"]), k
+            assert np.array_equal(b.cpu().numpy(), fx[k + "_b"]), k
+            assert np.array_equal(c.cpu().numpy(), fx[k + "_c"]), k

@@ -658,3 +658,63 @@ def test_pam_flash_backward_forms_agree_at_bench_and_max_size(gd):
             if form == L.PAM_BWD_K64_PARTS:
                 again = run(form)
                 assert all(torch.equal(a, b) for a, b in zip(got, again)), "K64 parts form must be bitwise reproducible"
+
+
+def test_inference_tile_180x88_and_postprocessing(gd):
+    """f3: the 0.05-degree inference call of test.ipynb (c1:149-167) -- eval-mode generator on a batch of FOUR 180 x 88
+    tiles (PAM over N = 15 840 tokens, ragged against every tile size of the kernels), bicubic x1.25, the x4 bicubic of
+    the low-resolution field and smooth_blend -- against the oracle's eval forward, ATen's F.interpolate and a numpy
+    restatement of smooth_blend (c1:87-101)"""
+    import numpy as np
+    import torch.nn.functional as F
+    from scipy.ndimage import gaussian_filter
+    from gan_danet_amd import inference as INF
+    from oracle import modules as OM
+    torch.manual_seed(5)
+    Cin, B, H, W = 8, 4, 180, 88
+    mo = OM.FlexibleUpsamplingModule(input_channels=Cin)
+    mo.apply(OM.weights_init_normal)
+    for n, p in mo.named_parameters():
+        if n.endswith("gamma"):
+            p.data.fill_(0.1)
+    mo.eval()
+    g = torch.Generator().manual_seed(6)
+    lr = torch.randn(B, 1, H, W, generator=g)
+    aux = torch.randn(B, Cin - 1, H, W, generator=g)
+    with torch.no_grad():
+        yo = mo(torch.cat([lr, aux], 1))
+    G = gd.FlexibleUpsamplingModule(input_channels=Cin)
+    G.load_state_dict(mo.state_dict())
+    G.to(DEV).eval()
+    with torch.no_grad(), gd.precision("fp32"):
+        y32 = G(torch.cat([lr, aux], 1).to(DEV))
+    with torch.no_grad(), gd.precision("bf16"):
+        y16 = G(torch.cat([lr, aux], 1).to(DEV))
+    assert tuple(y32.shape) == (B, 1, 4 * H, 4 * W)
+    assert_close(y32, yo, 1e-3, "eval forward 180x88 B=4 fp32")
+    assert_close(y16, yo, 5e-2, "eval forward 180x88 B=4 bf16", rell2)
+    # bicubic x1.25 / x4 against ATen
+    up = INF.bicubic_resize(y32, 1.25)
+    ref_up = F.interpolate(y32.cpu(), scale_factor=1.25, mode="bicubic", align_corners=False)
+    assert tuple(up.shape) == tuple(ref_up.shape) == (B, 1, 900, 440)
+    assert_close(up, ref_up, 2e-5, "bicubic x1.25")
+    hg = INF.bicubic_resize(lr.to(DEV), 4.0)
+    assert_close(hg, F.interpolate(lr, scale_factor=4, mode="bicubic", align_corners=False), 2e-5, "bicubic x4")
+    # smooth_blend (numpy restatement of test.ipynb c1:87-101)
+    region, sigma = (0, 90, 0, 44), 5
+    sr, er, sc, ec = region
+    mask = np.ones((er - sr, ec - sc), dtype=float)
+    mask[0:sigma, :] = np.linspace(0, 1, sigma)[:, None]
+    mask[-sigma:, :] = np.linspace(1, 0, sigma)[:, None]
+    mask[:, 0:sigma] = np.maximum(mask[:, 0:sigma], np.linspace(0, 1, sigma)[None, :])
+    mask[:, -sigma:] = np.maximum(mask[:, -sigma:], np.linspace(1, 0, sigma)[None, :])
+    mask = torch.tensor(gaussian_filter(mask, sigma=sigma), dtype=torch.float32)[None, None]
+    a, b = torch.randn(2, 1, 120, 60, generator=g), torch.randn(2, 1, 120, 60, generator=g)
+    want = a.clone()
+    want[:, :, sr:er, sc:ec] = a[:, :, sr:er, sc:ec] * (1 - mask) + b[:, :, sr:er, sc:ec] * mask
+    got = INF.smooth_blend(a.to(DEV), b.to(DEV), region, sigma)
+    assert_close(got, want, 1e-6, "smooth_blend")
+    # the whole loop body on the device; histogram matching at the notebook's weight 0.0 is the identity
+    out = INF.predict_batch(G, lr.to(DEV), aux.to(DEV), region=region)
+    assert tuple(out.shape) == (B, 1, 900, 440) and torch.isfinite(out).all()
+    assert INF.mild_histogram_matching(up, lr.to(DEV), 0.0) is up

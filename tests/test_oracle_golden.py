@@ -304,3 +304,31 @@ def test_init_moments(golden_dir):
             p = params[name]
             assert abs(p.std().item() - float(sd)) < 0.12 * float(sd)
     assert float(G.attention_modules[0].position_attention.gamma) == 0.0
+
+
+def test_customdataset_restatement_vs_reference_fixture(golden_dir):
+    """f2 pin: oracle.data.CustomDataset / batches against the tensors the REFERENCE's CustomDataset and DataLoader
+    returned (tests/golden/make_golden_data.py), bit for bit, including the order of the `random` / `torch.randn_like`
+    draws of apply_augmentation (datasets.py:181-208)"""
+    import random
+    import numpy as np
+    from oracle import data as OD
+    fx = np.load(os.path.join(golden_dir, "customdataset_6x8x8.npz"))
+    ds = OD.CustomDataset(fx["lr_grace_05"], fx["lr_grace_025"], fx["hr_aux"], augment=False)
+    assert len(ds) == int(fx["length"])
+    a, b, c = ds[2]
+    assert np.array_equal(a.numpy(), fx["plain_a"]) and np.array_equal(b.numpy(), fx["plain_b"]) and np.array_equal(c.numpy(), fx["plain_c"])
+    for i, (ba, bb, bc) in enumerate(OD.batches(ds, 4)):
+        assert np.array_equal(ba.numpy(), fx[f"batch{i}_a"]) and np.array_equal(bb.numpy(), fx[f"batch{i}_b"])
+        assert np.array_equal(bc.numpy(), fx[f"batch{i}_c"])
+    assert i == 1
+    dsa = OD.CustomDataset(fx["lr_grace_05"], fx["lr_grace_025"], fx["hr_aux"], augment=True)
+    random.seed(int(fx["seed_random"]))
+    torch.manual_seed(int(fx["seed_torch"]))
+    for rep in range(2):
+        for i in range(len(dsa)):
+            a, b, c = dsa[i]
+            k = f"aug{rep}_{i}"
+            assert np.array_equal(a.numpy(), fx[k + "_a"]), k
+            assert np.array_equal(b.numpy(), fx[k + "_b"]), k
+            assert np.array_equal(c.numpy(), fx[k + "_c"]), k
