@@ -115,6 +115,8 @@ SIGNATURES = {
     "gd_shift_sum9_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gd_shift_sum9_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "gd_combine_inputs": (_i, [_p, _i, _i, _i, _f, _p, _i, _i, _i, _f, _p, _i, _i, _i, _p]),
+    "gd_hist_match_ws_bytes": (_sz, [_l, _l]),
+    "gd_hist_match": (_i, [_p, _p, _i, _l, _l, C.c_double, _p, _p, _sz, _p]),
     "gd_blend_region": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gd_augment_d4": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _f, _p]),
     "gd_bcast_mul": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),

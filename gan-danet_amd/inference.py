@@ -50,13 +50,14 @@ def smooth_blend(hr_generated: torch.Tensor, hr_grace: torch.Tensor, region: Seq
 
 
 def mild_histogram_matching(hr_generated: torch.Tensor, lr_grace_025: torch.Tensor, weight: float = 0.0) -> torch.Tensor:
-    """c1:69-85 ``apply_mild_histogram_matching``: ``(1 - weight) * source + weight * matched``.  The notebook calls it
-    with ``weight = 0.0`` (c1:161), where the result IS the source; that case returns the input.  A non-zero weight
-    needs the per-sample sort / quantile interpolation, which is not built (it raises rather than approximate)."""
+    """c1:69-85 ``apply_mild_histogram_matching``: per sample, ``(1 - weight) * source + weight * matched`` where
+    ``matched`` maps the sample's empirical CDF onto the reference field's (np.unique / np.interp semantics).  The
+    notebook calls it with ``weight = 0.0`` (c1:161), where the result IS the source: that case returns the input
+    untouched.  Otherwise one launch sequence per sample (``gd_hist_match``: radix sorts + a quantile-interpolation
+    kernel); the result is float64, as the notebook's numpy code returns."""
     if weight == 0.0:
         return hr_generated
-    raise NotImplementedError("mild_histogram_matching with weight != 0: the notebook's call uses weight = 0.0 "
-                              "(test.ipynb c1:161); the sort-based matching is not built")
+    return K.hist_match(hr_generated.contiguous(), lr_grace_025.contiguous(), weight)
 
 
 @torch.no_grad()
@@ -69,6 +70,8 @@ def predict_batch(model: torch.nn.Module, lr_grace_025: torch.Tensor, aux: torch
     xin = torch.cat([lr_grace_025, aux], dim=1)                          # layout copy
     yhat = bicubic_resize(model(xin), upscale)
     yhat = mild_histogram_matching(yhat, lr_grace_025, hist_weight)
+    if yhat.dtype != torch.float32:          # the notebook continues in float64 from here; the blend kernel is fp32
+        yhat = yhat.float()
     hr_grace = bicubic_resize(lr_grace_025, blend_with)
     sr, er, sc, ec = region
     if yhat.shape == hr_grace.shape:

@@ -342,6 +342,21 @@ def combine_inputs(lr: Tensor, aux: Tensor, s1: float = 0.5, s2: float = 0.25) -
     return out
 
 
+def hist_match(src: Tensor, ref: Tensor, weight: float) -> Tensor:
+    """per-sample mild histogram matching (test.ipynb c1:69-85); src (B, ...), ref (B, ...) fp32 -> fp64 like src"""
+    _dense(src, "histogram source"), _dense(ref, "histogram reference")
+    B = src.shape[0]
+    if ref.shape[0] != B:
+        raise L.GandanetError("hist_match: batch sizes differ")
+    ns, nt = src[0].numel(), ref[0].numel()
+    nbytes = int(lib().gd_hist_match_ws_bytes(ns, nt))
+    ws = torch.empty(nbytes, device=src.device, dtype=torch.uint8)
+    out = torch.empty(src.shape, device=src.device, dtype=torch.float64)
+    L.check(lib().gd_hist_match(_ptr(src), _ptr(ref), B, ns, nt, float(weight), _ptr(out), _ptr(ws), nbytes, _stream()),
+            "gd_hist_match")
+    return out
+
+
 def blend_region(gen: Tensor, grace: Tensor, mask: Tensor, region) -> Tensor:
     """in place on ``gen``: gen[.., sr:er, sc:ec] = gen * (1 - mask) + grace * mask"""
     _dense(gen, "blend target"), _dense(grace, "blend source"), _dense(mask, "blend mask")

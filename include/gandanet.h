@@ -312,6 +312,13 @@ int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void*
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
                      float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream);
 
+/* test.ipynb c1:69-85 mild_histogram_matching, per sample of a batch: out[b] = (1 - weight) * src[b] + weight *
+ * interp(cdf_src(src[b]), cdf_ref, sorted unique ref[b]) with numpy's np.unique / np.interp semantics (float64 result, as
+ * the notebook produces).  src (B, ns), ref (B, nt) fp32; out (B, ns) fp64; ws: caller-owned scratch of
+ * gd_hist_match_ws_bytes(ns, nt) bytes (sort buffers).  One radix sort pair per sample (rocPRIM via hipCUB). */
+size_t gd_hist_match_ws_bytes(long ns, long nt);
+int gd_hist_match(const float* src, const float* ref, int B, long ns, long nt, double weight, double* out, void* ws,
+                  size_t ws_bytes, void* stream);
 /* test.ipynb c1:87-101 smooth_blend: over the region rows [sr, er) x columns [sc, ec) of every (b, c) plane,
  * gen = gen * (1 - mask) + grace * mask, in place; mask (er-sr, ec-sc) fp32 is the feathered window the host builds. */
 int gd_blend_region(float* gen, const float* grace, const float* mask, int BC, int H, int W, int sr, int er, int sc,

@@ -718,3 +718,35 @@ def test_inference_tile_180x88_and_postprocessing(gd):
     out = INF.predict_batch(G, lr.to(DEV), aux.to(DEV), region=region)
     assert tuple(out.shape) == (B, 1, 900, 440) and torch.isfinite(out).all()
     assert INF.mild_histogram_matching(up, lr.to(DEV), 0.0) is up
+
+
+def test_mild_histogram_matching_vs_numpy_restatement(gd):
+    """f3: apply_mild_histogram_matching (test.ipynb c1:69-85) with a non-zero weight, against the notebook's numpy
+    code restated here (np.unique / cumsum / np.interp): continuous data, heavily tied data (quantised values: runs of
+    equal source AND reference values), different source / reference sizes.  float64 result; bracket decisions are
+    exact, so agreement is to double round-off"""
+    import numpy as np
+    from gan_danet_amd import inference as INF
+
+    def ref_impl(source, reference, weight):
+        oldshape = source.shape
+        source, reference = source.ravel(), reference.ravel()
+        s_vals, bin_idx, s_counts = np.unique(source, return_inverse=True, return_counts=True)
+        t_vals, t_counts = np.unique(reference, return_counts=True)
+        s_q = np.cumsum(s_counts).astype(np.float64) / np.sum(s_counts)
+        t_q = np.cumsum(t_counts).astype(np.float64) / np.sum(t_counts)
+        matched = np.interp(s_q, t_q, t_vals)[bin_idx].reshape(oldshape)
+        return ((1 - weight) * source + weight * matched.ravel()).reshape(oldshape)
+
+    rs = np.random.RandomState(3)
+    cases = [
+        (rs.randn(3, 1, 45, 22).astype(np.float32), (rs.randn(3, 1, 36, 18) * 2 + 1).astype(np.float32), 0.35),
+        (np.round(rs.randn(2, 1, 40, 20) * 4).astype(np.float32) / 4, np.round(rs.randn(2, 1, 20, 10) * 3).astype(np.float32), 1.0),
+        (rs.rand(2, 2, 16, 16).astype(np.float32), np.full((2, 1, 8, 8), 0.5, np.float32), 0.6),
+    ]
+    for src, ref, w in cases:
+        want = np.array([ref_impl(h, l, w) for h, l in zip(src, ref)])
+        got = INF.mild_histogram_matching(torch.from_numpy(src).to(DEV), torch.from_numpy(ref).to(DEV), w)
+        assert got.dtype == torch.float64 and tuple(got.shape) == src.shape
+        err = np.abs(got.cpu().numpy() - want).max() / (np.abs(want).max() + 1e-30)
+        assert err <= 1e-12, f"histogram matching rel err {err:.2e} (weight {w})"
