@@ -199,18 +199,40 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             voff[i] = (unsigned int)lane * 16u;             // 1 KiB = this tile's constants + the next three tiles' (unused)
         }
     }
-    auto dma_tile = [&](int t, int slot) {
-        const char* qb = reinterpret_cast<const char*>(qt + (nb + (long)t * 32) * 32);
-        const char* db = reinterpret_cast<const char*>(dot_ + (nb + (long)t * 32) * CP);
-        const char* rb = reinterpret_cast<const char*>(rc + ((long)b * nqt + t) * 64);
+    // wave-uniform source pointer of each of this wave's pieces for the NEXT tile to prefetch, and its per-tile
+    // advance: they live in SGPRs and move by one add per piece and tile (no per-tile index arithmetic)
+    const char* pbase[PPW];
+    long padv[PPW];
+    int pdst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        int piece = wave + 4 * i;
+        if (piece >= NPIECE) piece = NPIECE - 2;
+        pdst[i] = piece * 512;
+        if (piece < 3) {
+            pbase[i] = reinterpret_cast<const char*>(qt + nb * 32);
+            padv[i] = 32 * 32 * 2;
+        } else if (piece < NPIECE - 1) {
+            pbase[i] = reinterpret_cast<const char*>(dot_ + nb * CP);
+            padv[i] = 32 * CP * 2;
+        } else {
+            pbase[i] = reinterpret_cast<const char*>(rc + (long)b * nqt * 64);
+            padv[i] = 64 * 4;
+        }
+    }
+    auto dma_seek = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) pbase[i] += (long)t * padv[i];
+    };
+    // issue the DMA of the tile the pointers stand on into ring slot `slot`, then step to tile `t + 1` (wrapping)
+    auto dma_next = [&](int t, int slot) {
+        const long step = (t + 1 == nqt) ? -(long)(nqt - 1) : 1;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            int piece = wave + 4 * i;
-            if (piece >= NPIECE) piece = NPIECE - 2;
-            unsigned short* dst = lds + slot * SLOT + piece * 512;     // wave-uniform piece base
-            const char* base = piece < 3 ? qb : piece < NPIECE - 1 ? db : rb;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[i]),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            unsigned short* dst = lds + slot * SLOT + pdst[i];           // wave-uniform piece base
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pbase[i] + voff[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            pbase[i] += step * padv[i];
         }
     };
 
@@ -273,11 +295,12 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     };
 
-    {
-        dma_tile(tcur, 0);
-        dma_tile(next_tile(tcur), 1);
-    }
-    int tpf = next_tile(next_tile(tcur));   // next tile to prefetch
+    dma_seek(tcur);
+    int tpf = tcur;                          // the tile the DMA pointers stand on
+    dma_next(tpf, 0);
+    tpf = next_tile(tpf);
+    dma_next(tpf, 1);
+    tpf = next_tile(tpf);
 
     for (int it = 0; it < nqt; ++it) {
         // tile `it` landed: this wave's pieces by its own counted wait, the other waves' by the barrier behind it.
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         // VMEM order per iteration (the vmcnt count above relies on it): DMA of tile it+2 into the slot of tile it-1
         // (every wave is past its reads of it: it is past this barrier), THEN the dQ hand-over of tile it-1
         if constexpr (!DMA_LATE) {
-            dma_tile(tpf, (it + 2) % NSLOT);
+            dma_next(tpf, (it + 2) % NSLOT);
             tpf = next_tile(tpf);
         }
         if constexpr (!HANDOVER_MID) dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             sacc[1] = mfma16<F16>(qa, kfB[1][s], sacc[1]);
         }
         if constexpr (DMA_LATE) {
-            dma_tile(tpf, (it + 2) % NSLOT);
+            dma_next(tpf, (it + 2) % NSLOT);
             tpf = next_tile(tpf);
         }
         // dP = dO V^T - delta
