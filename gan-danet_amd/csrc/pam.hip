@@ -19,8 +19,10 @@
 //   it sweeps the queries in 32-row tiles; S and dP are computed with the key on the lane, so P and dS are directly
 //   the B operands of dV^T += dO^T P and dK^T += Q^T dS.  For dQ the dS tile is turned around through wave-private
 //   LDS (transpose read), multiplied by the wave's K rows and the workgroup's sum is stored as a bf16 part per key
-//   block; pam_dq_reduce_kernel adds the key blocks.  No atomics anywhere.  (pam_bwd_dq_kernel: the scratch-free
-//   alternative, a query-parallel kernel that recomputes S and dP.)
+//   block; pam_dq_reduce_kernel adds the key blocks.  No atomics in this file's kernels.  (pam_bwd_dq_kernel: the
+//   scratch-free alternative, a query-parallel kernel that recomputes S and dP.)  The DEFAULT backward is the K64 kernel
+//   of pam_bwd64.hip (64 keys per wave, one wave per SIMD, fp32 atomics or deterministic parts for dQ); the kernels
+//   here are its reproducible / scratch-free fallbacks (gd_pam_flash_bwd forms 2 and 3).
 #include <stdlib.h>
 
 #include "pam_common.h"

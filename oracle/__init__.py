@@ -24,8 +24,8 @@ oracle therefore runs on this image's torch 2.10 CPU kernels.
 Pinning status: the reference ships NO tests, golden vectors or fixtures for
 this path.  The oracle is pinned instead against outputs
 of the reference itself, imported by file path in the build container
-(``oracle/pin_against_reference.py``; fixtures + generating script under
-``tests/golden/``).  ``PerceptualLoss`` cannot be constructed from the
+(generating scripts ``tests/golden/make_golden.py``, ``make_golden_a14.py``, ``make_golden_data.py``; the fixtures
+they wrote sit next to them and ``tests/test_oracle_golden.py`` checks every oracle function against them).  ``PerceptualLoss`` cannot be constructed from the
 reference here (needs torchvision, absent): that one term is
 "parity unpinned" -- restated from losses.py:13-73 plus the published VGG19
 "E" feature stack, and checked oracle-vs-HIP only.

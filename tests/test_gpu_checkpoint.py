@@ -22,7 +22,7 @@ def _make(gd, seed=0):
     return G, D
 
 
-def test_resume_is_bit_exact_and_generator_file_has_reference_keys(tmp_path, golden_dir):
+def test_resume_matches_uninterrupted_run_and_generator_file_has_reference_keys(tmp_path, golden_dir):
     import gan_danet_amd as gd
     from gan_danet_amd import checkpoint as C
     from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
@@ -92,3 +92,31 @@ def test_early_stopping_rule_and_ensemble_helpers(tmp_path):
         members.append(Gi.eval())
     mean, std = C.predict_ensemble(members, x)
     assert tuple(mean.shape) == (1, 1, 64, 64) and torch.isfinite(mean).all() and (std > 0).any()
+
+
+def test_resume_is_bit_exact_in_deterministic_mode(tmp_path):
+    """gd.set_deterministic(True) (no atomic split reductions; PAM dQ through bf16 parts): a run resumed from the
+    full-state checkpoint continues BIT FOR BIT like the uninterrupted one (bf16 mode, the fused PAM kernels)"""
+    import gan_danet_amd as gd
+    from gan_danet_amd import checkpoint as C
+    x, tgt = seeded((2, 8, 16, 16), 171).to(DEV), seeded((2, 1, 64, 64), 172).to(DEV)
+    gd.set_deterministic(True)
+    try:
+        with gd.precision("bf16"):
+            G, D = _make(gd)
+            tr = gd.GanTrainer(G, D, None)
+            tr.step(x, tgt, 0.25)
+            path = str(tmp_path / "state.pt")
+            C.save_training_state(path, tr, epoch=1)
+            out_a = tr.step(x, tgt, 0.5)
+            G2, D2 = _make(gd, seed=123)
+            tr2 = gd.GanTrainer(G2, D2, None)
+            C.load_training_state(path, tr2)
+            out_b = tr2.step(x, tgt, 0.5)
+    finally:
+        gd.set_deterministic(False)
+    assert torch.equal(out_a.loss_g, out_b.loss_g) and torch.equal(out_a.loss_d, out_b.loss_d)
+    for (k, a), b in zip(G.state_dict().items(), G2.state_dict().values()):
+        assert torch.equal(a, b), k
+    for (k, a), b in zip(D.state_dict().items(), D2.state_dict().values()):
+        assert torch.equal(a, b), k
