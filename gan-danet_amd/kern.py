@@ -72,6 +72,7 @@ USE_CONV3X3_FAST = True   # route eligible 3x3/s1/p1 bf16 convs to the LDS-patch
 
 # ---- optional HIP-event brackets around the hot kernels (bench.py's live roofline measurement) -------------
 PROFILE_ON = False
+PROFILE_CONV = os.environ.get("GD_PROFILE_CONV", "0") == "1"     # also bracket every conv call, keyed by its shape
 PROFILE: list = []   # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
 
 
@@ -93,6 +94,19 @@ class _Bracket:
             self.e1.record()
             PROFILE.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
         return False
+
+
+class _ConvBracket(_Bracket):
+    """opt-in (GD_PROFILE_CONV=1) per-shape bracket of a convolution call: name = kind k s Cin->Cout @HoxWo"""
+
+    def __init__(self, kind, k, stride, cin, cout, ho, wo, b):
+        super().__init__(f"conv_{kind}_k{k}s{stride}_{cin}->{cout}@{ho}x{wo}", 2.0 * k * k * cin * cout * ho * wo * b)
+
+    def __enter__(self):
+        return super().__enter__() if PROFILE_CONV else self
+
+    def __exit__(self, *exc):
+        return super().__exit__(*exc) if PROFILE_CONV else False
 
 
 def profile_summary():
@@ -155,10 +169,11 @@ def conv2d_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int, pad: i
         out = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != (B, Cout, Ho, Wo):
         raise L.GandanetError("conv2d: bad out shape")
-    conv_nn(B=B, M=Cout, Ck=Cin, ks=k, stride=stride, pad=pad, transposed=False, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo,
-            a=w, a_bs=0, a_sm=Cin * k * k, a_sc=k * k, a_st=1, x=x, x_bs=xbs, y=out, y_bs=_bview(out, "conv out"),
-            precision=precision, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, bias=bias, act=act,
-            accumulate=accumulate)
+    with _ConvBracket("fwd", k, stride, Cin, Cout, Ho, Wo, B):
+        conv_nn(B=B, M=Cout, Ck=Cin, ks=k, stride=stride, pad=pad, transposed=False, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo,
+                a=w, a_bs=0, a_sm=Cin * k * k, a_sc=k * k, a_st=1, x=x, x_bs=xbs, y=out, y_bs=_bview(out, "conv out"),
+                precision=precision, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, bias=bias, act=act,
+                accumulate=accumulate)
     return out
 
 
@@ -173,9 +188,10 @@ def conv2d_dgrad(dy: Tensor, w: Tensor, in_hw: Tuple[int, int], stride: int, pad
         raise L.GandanetError("conv2d_dgrad: weight/out-channel mismatch")
     if out is None:
         out = torch.empty(B, Cin, Hi, Wi, device=dy.device, dtype=torch.float32)
-    conv_nn(B=B, M=Cin, Ck=Cout, ks=k, stride=stride, pad=pad, transposed=True, Hi=Ho, Wi=Wo, Ho=Hi, Wo=Wi,
-            a=w, a_bs=0, a_sm=k * k, a_sc=Cin * k * k, a_st=1, x=dy, x_bs=dbs, y=out, y_bs=_bview(out, "conv dx"),
-            precision=precision, accumulate=accumulate, alpha=alpha)
+    with _ConvBracket("dgrad", k, stride, Cin, Cout, Ho, Wo, B):
+        conv_nn(B=B, M=Cin, Ck=Cout, ks=k, stride=stride, pad=pad, transposed=True, Hi=Ho, Wi=Wo, Ho=Hi, Wo=Wi,
+                a=w, a_bs=0, a_sm=k * k, a_sc=Cin * k * k, a_st=1, x=dy, x_bs=dbs, y=out, y_bs=_bview(out, "conv dx"),
+                precision=precision, accumulate=accumulate, alpha=alpha)
     return out
 
 
@@ -204,6 +220,12 @@ def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision
     B, Cout, Ho, Wo = dy.shape
     _, Cin, Hi, Wi = x.shape
     dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
+    with _ConvBracket("wgrad", k, stride, Cin, Cout, Ho, Wo, B):
+        return _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu, dw, dbs, xbs, B, Cout, Cin, Hi,
+                             Wi, Ho, Wo)
+
+
+def _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu, dw, dbs, xbs, B, Cout, Cin, Hi, Wi, Ho, Wo):
     if USE_CONV3X3_FAST and k == 3 and stride in (1, 2) and pad == 1 and precision == L.PREC_BF16:
         dy16 = None
         if Cout > 32 and Cin >= 4 * 32:
