@@ -499,6 +499,7 @@ struct WgradArgs {
     const unsigned short* dy16;      // optional bf16 copy of dy, dense (B, M, Ho, Wo): read instead of dy
     const float* dy; long dy_bs;
     const float* x; long x_bs;
+    const unsigned short* x16; int x16_ld;   // optional pixel-major bf16 copy of x, dense (B, H, W, x16_ld): read instead of x
     const float* in_scale; const float* in_shift; int in_relu;
     float* dw;
     int B, M, Ck, H, W, Ho, Wo;
@@ -588,7 +589,25 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
             w.y = gd_pack_bf2(f.z, f.w);
             *reinterpret_cast<uint2*>(dys + m * DYLD + v * 4) = w;
         }
-        // ---- input patch -> [pixel][ci] bf16 (fused BN affine + ReLU): item = (patch pixel, channel half) ----
+        // ---- input patch -> [pixel][ci] bf16 ----
+        // pixel-major bf16 source (gd_pack_16 transposed output): a patch pixel's 32-channel chunk is 64 contiguous
+        // bytes, so an item = (patch pixel, channel octet) is ONE 16-byte load and ONE 16-byte LDS store -- against 16
+        // strided 4-byte loads, 8 converts and 8 stores per item of the fp32 NCHW path below
+        if (a.x16) {
+            for (int w = tid; w < 4 * NCH * NPIXk; w += NT) {
+                const int oc = w / NPIXk;                   // (chunk, octet)
+                const int q = oc & 3, chk = oc >> 2;
+                const int pix = w - oc * NPIXk;
+                const int py = pix / PWk, px = pix - py * PWk;
+                const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
+                const int cb = c0 + chk * CK + q * 8;
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cb < a.x16_ld)
+                    v = *reinterpret_cast<const u32x4_t*>(a.x16 + (((long)b * a.H + iy) * a.W + ix) * a.x16_ld + cb);
+                *reinterpret_cast<u32x4_t*>(patch + (chk * NPIXk + pix) * LD + q * 8) = v;
+            }
+        } else
+        // fp32 NCHW source (fused BN affine + ReLU): item = (patch pixel, channel half)
         for (int w = tid; w < 2 * NCH * NPIXk; w += NT) {
             const int hc = w / NPIXk;                   // (chunk, channel half)
             const int half = hc & 1, chk = hc >> 1;
@@ -661,9 +680,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
 // dw (Cout, Cin, 3, 3) fp32 is overwritten.  Same input-transform contract as gd_conv2d.
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
-                                const float* in_scale, const float* in_shift, int in_relu, int B, int Cout, int Cin, int H,
-                                int W, int stride, float* dw, void* stream) {
+                                const void* x_nhwc16, int x_ld, const float* in_scale, const float* in_shift, int in_relu,
+                                int B, int Cout, int Cin, int H, int W, int stride, float* dw, void* stream) {
     GD_CHECK_ARG(dy && x && dw, "gd_conv3x3_wgrad: null pointer");
+    GD_CHECK_ARG(!x_nhwc16 || (!in_scale && x_ld >= Cin && x_ld % 8 == 0),
+                 "gd_conv3x3_wgrad: the pixel-major bf16 x needs x_ld >= Cin, x_ld % 8 == 0 and no input transform");
     GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gd_conv3x3_wgrad: bad sizes");
     GD_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gd_conv3x3_wgrad: in_scale/in_shift must come together");
     hipStream_t s = (hipStream_t)stream;
@@ -671,6 +692,7 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16
     WgradArgs a;
     a.dy16 = (const unsigned short*)dy_bf16;
     a.dy = dy; a.dy_bs = dy_bs; a.x = x; a.x_bs = x_bs;
+    a.x16 = (const unsigned short*)x_nhwc16; a.x16_ld = x_ld;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
     a.dw = dw; a.B = B; a.M = Cout; a.Ck = Cin; a.H = H; a.W = W;
     a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;     // 3x3, pad 1

@@ -92,10 +92,13 @@ int gd_conv3x3(const gd_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
 /* weight gradient of the same convolution (bf16 MFMA, fp32 atomics across the pixel splits):
  * dw (Cout, Cin, 3, 3) = sum_{b,p} dy[b][co][p] * relu?(x*in_scale + in_shift)[b][ci][p (+) tap]; dw is overwritten.
  * dy_bf16 (may be NULL): a dense bf16 copy (B, Cout, Ho, Wo) of dy made by the caller (gd_pack_bf16); it is then read
- * instead of dy -- worth it when Cin spans several 32-channel chunks, each of which re-reads every dY tile. */
-int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs, const float* in_scale,
-                     const float* in_shift, int in_relu, int B, int Cout, int Cin, int H, int W, int stride, float* dw,
-                     void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
+ * instead of dy -- worth it when Cin spans several 32-channel chunks, each of which re-reads every dY tile.
+ * x_nhwc16 (may be NULL; needs in_scale == NULL): a dense PIXEL-MAJOR bf16 copy (B, H, W, x_ld) of x (the transposed
+ * output of gd_pack_bf16, x_ld = Cin rounded up to 8); the patch staging is then 16-byte copies instead of strided
+ * 4-byte gathers + converts -- worth it for wide convs (the 2C -> C fuse convs of DANetAttention). */
+int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs, const void* x_nhwc16,
+                     int x_ld, const float* in_scale, const float* in_shift, int in_relu, int B, int Cout, int Cin, int H,
+                     int W, int stride, float* dw, void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
 
 /* ------------------------------------------------------------------------------------------
  * "NT" GEMM with the long reduction split over workgroups:
