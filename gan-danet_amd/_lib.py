@@ -106,6 +106,14 @@ SIGNATURES = {
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gd_disc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _f, _p, _p]),
+    "gd_disc_stem_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "gd_disc_stem_dgrad": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "gd_conv3x3_nhwc_s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "gd_conv3x3_nhwc_s2_dgrad": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
+    "gd_nhwc_flatten_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
+    "gd_nhwc_flatten_bwd": (_i, [_p, _p, _f, _i, _i, _i, _p, _p]),
+    "gd_nhwc_to_nchw16": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "gd_nhwc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "gd_nhwc_stem_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "gd_nhwc_maxpool2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libgandanet_hip.so")
-SOURCES = ["api.hip", "gemm_conv.hip", "conv3x3.hip", "gemm_nt.hip", "norm.hip", "resample.hip", "pointwise.hip", "nhwc.hip", "pam.hip", "pam_bwd64.hip", "comm.hip", "histmatch.hip"]
+SOURCES = ["api.hip", "gemm_conv.hip", "conv3x3.hip", "gemm_nt.hip", "norm.hip", "resample.hip", "pointwise.hip", "nhwc.hip", "disc_nhwc.hip", "pam.hip", "pam_bwd64.hip", "comm.hip", "histmatch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

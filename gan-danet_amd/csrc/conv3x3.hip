@@ -264,19 +264,22 @@ struct NhwcConvArgs {
     const unsigned short* x;      // (B, H, W, K) bf16
     const unsigned short* wp;     // packed weights [m-tile][chunk][tap][BM][32]
     const float* bias;            // (M) or null
-    const unsigned short* mask;   // (B, H, W, M) bf16 or null
-    const unsigned short* res;    // (B, H, W, M) bf16 or null
-    unsigned short* y;            // (B, H, W, M) bf16
-    int H, W, K, M, relu, tiles_x, nchunks;
+    const unsigned short* mask;   // (B, Ho, Wo, M) bf16 or null
+    const unsigned short* res;    // (B, Ho, Wo, M) bf16 or null
+    unsigned short* y;            // (B, Ho, Wo, M) bf16
+    int H, W, Ho, Wo, K, M, act, tiles_x, nchunks;   // act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
+    float slope;
 };
 
-template <int BM>
+// S = stride (1: VGG stack; 2: the down-sampling convs of Discriminator1, discriminator.py:60-63 -- the patch of a
+// 4 x 32 output tile is then 9 x 65 input pixels and consecutive output pixels read patch pixels two apart)
+template <int BM, int S>
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs a) {
-    constexpr int TH = 8;
+    constexpr int TH = S == 1 ? 8 : 4;
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int TM = BM / (32 * WAVES_M);
     constexpr int TN = TH / WAVES_N;
-    constexpr int PH = TH + 2, NPIX = PH * PW;
+    constexpr int PH = S * (TH - 1) + 3, PWk = S * (TW - 1) + 3, NPIX = PH * PWk;
     constexpr int WCHUNKS = 3 * BM * CK / 8;
     constexpr int WPT = WCHUNKS / 256;
     constexpr int NIT = (4 * NPIX + 255) / 256;       // 16-byte staging items (pixel, channel octet) per thread
@@ -326,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
     for (int it = 0; it < NIT; ++it) {
         const int w = tid + it * 256;
         const int pix = w >> 2, q = w & 3;
-        const int py = pix / PW, px = pix - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const int py = pix / PWk, px = pix - py * PWk;
+        const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
         const bool slot = w < 4 * NPIX;
         const bool inside = slot && iy >= 0 && iy < H && ix >= 0 && ix < W;
         loff[it] = pix * LD + q * 8;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
                                                                   ks * 16 + 8 * h);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + ((wn * TN + j + ky) * PW + r + kx) * LD +
+                        fb[j] = *reinterpret_cast<const bf16x8_t*>(patch + (((wn * TN + j) * S + ky) * PWk + r * S + kx) * LD +
                                                                   ks * 16 + 8 * h);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -390,12 +393,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
 
     // ---- epilogue: lane = pixel, accumulator registers 4g..4g+3 = four consecutive output channels (8-byte stores) ----
     const int ox = x0 + r;
-    if (ox < W) {
+    if (ox < a.Wo) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int oy = y0 + wn * TN + j;
-            if (oy >= H) continue;
-            const long pbase = (((long)b * H + oy) * W + ox) * a.M;
+            if (oy >= a.Ho) continue;
+            const long pbase = (((long)b * a.Ho + oy) * a.Wo + ox) * a.M;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
                     for (int k = 0; k < 4; ++k) {
                         v[k] = acc[i][j][4 * g + k];
                         if (a.bias) v[k] += a.bias[m + k];
-                        if (a.relu) v[k] = fmaxf(v[k], 0.f);
+                        if (a.act == 1) v[k] = fmaxf(v[k], 0.f);
+                        else if (a.act == 2) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
                     }
                     if (a.mask) {
                         const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + pbase + m);
@@ -433,23 +437,209 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
     }
 }
 
+// Data gradient of the stride-2 convolution on NHWC bf16, split by the PARITY of the input pixel (Y, X) = (2u+py, 2v+px):
+//   dX[Y][X][ci] = sum over taps (ky, kx) with ky = py+1 (mod 2), kx = px+1 (mod 2) and co of
+//                  W[co][ci][ky][kx] * dY[(Y+1-ky)/2][(X+1-kx)/2][co]
+// so class (0,0) has one tap, (0,1)/(1,0) two and (1,1) four: nine MFMA tap passes in all, none of them multiplying
+// the zeros a dilated (stride-1 over an up-sampled dY) formulation would.  A workgroup owns a 4 x 32 tile of (u, v)
+// = 8 x 64 input pixels and 64 input channels; it stages the 5 x 33 dY patch per 32-channel chunk of co once and
+// keeps the four parity classes in 4 x TN accumulators.  Operator image: wp[m-tile][chunk][tap][64][32] with m = ci,
+// c = co, taps NOT flipped (gd_conv3x3_nhwc_pack(transposed = 2)).
+// Epilogue: * LeakyReLU'(act) where act (B, H, W, K) is the OUTPUT of the activation that produced this conv's input.
+struct NhwcDgrad2Args {
+    const unsigned short* dy;     // (B, Ho, Wo, M) bf16
+    const unsigned short* wp;
+    const unsigned short* act;    // (B, H, W, K) bf16 or null
+    unsigned short* dx;           // (B, H, W, K) bf16
+    int H, W, Ho, Wo, K, M, tiles_x, nchunks;
+    float slope;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_dgrad2_kernel(const NhwcDgrad2Args a) {
+    constexpr int BM = 64, TH = 4;
+    constexpr int TN = TH / 2;                     // dY rows per wave
+    constexpr int PH = TH + 1, PWd = TW + 1, NPIX = PH * PWd;
+    constexpr int WPT = 3 * BM * CK / 8 / 256;     // 3
+    constexpr int NIT = (4 * NPIX + 255) / 256;    // 3
+
+    __shared__ __attribute__((aligned(16))) unsigned short patch[NPIX * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short wts[3 * BM * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z, mt = blockIdx.y;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int u0 = ty * TH, v0 = tx * TW;
+    const int Ho = a.Ho, Wo = a.Wo, M = a.M;
+    const unsigned short* dyimg = a.dy + (long)b * Ho * Wo * M;
+
+    f32x16_t acc[4][TN];                           // [parity class 2 py + px][dY row of this wave]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
+
+    const unsigned short* wbase = a.wp + (long)mt * a.nchunks * 9 * BM * CK;
+    u32x4_t wreg[WPT];
+    auto load_w = [&](int chunk, int ky) {
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(wbase + ((long)chunk * 9 + ky * 3) * BM * CK);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[i] = src[tid + i * 256];
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int v = tid + i * 256;
+            *reinterpret_cast<u32x4_t*>(wts + (v >> 2) * LD + (v & 3) * 8) = wreg[i];
+        }
+    };
+
+    unsigned int goff[NIT], inmask = 0, slotmask = 0;
+    int loff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int w = tid + it * 256;
+        const int pix = w >> 2, q = w & 3;
+        const int py = pix / PWd, px = pix - py * PWd;
+        const int iy = u0 + py, ix = v0 + px;
+        const bool slot = w < 4 * NPIX;
+        const bool inside = slot && iy < Ho && ix < Wo;
+        loff[it] = pix * LD + q * 8;
+        goff[it] = inside ? (unsigned int)(((long)iy * Wo + ix) * M + q * 8) : 0u;
+        inmask |= inside ? (1u << it) : 0u;
+        slotmask |= slot ? (1u << it) : 0u;
+    }
+    u32x4_t raw[NIT];
+    auto load_patch = [&](int chunk) {
+        const unsigned short* base = dyimg + chunk * CK;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = (tid + it * 256) & 3;
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            raw[it] = (((inmask >> it) & 1u) && chunk * CK + q * 8 < M) ? *reinterpret_cast<const u32x4_t*>(base + goff[it]) : z;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if ((slotmask >> it) & 1u) *reinterpret_cast<u32x4_t*>(patch + loff[it]) = raw[it];
+    };
+
+    load_patch(0);
+    store_patch();
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        load_w(chunk, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            store_w();
+            __syncthreads();
+            if (ky == 0 && chunk + 1 < a.nchunks) load_patch(chunk + 1);
+            if (ky < 2) load_w(chunk, ky + 1);
+            // tap row ky serves input rows of parity py = (ky + 1) & 1 from dY row u + oy, oy = (ky == 0)
+            const int py = (ky + 1) & 1, oy = ky == 0 ? 1 : 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int px = (kx + 1) & 1, ox = kx == 0 ? 1 : 0;
+#pragma unroll
+                for (int ks = 0; ks < CK / 16; ++ks) {
+                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(wts + (kx * BM + wm * 32 + r) * LD + ks * 16 + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(
+                            patch + ((wn * TN + j + oy) * PWd + r + ox) * LD + ks * 16 + 8 * h);
+                        acc[2 * py + px][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_native_t, fa), __builtin_bit_cast(bf16x8_native_t, fb),
+                            acc[2 * py + px][j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (chunk + 1 < a.nchunks) store_patch();
+    }
+
+    // ---- epilogue: lane = dY column v0 + r -> input pixels X = 2 (v0 + r) + px; 8-byte stores of 4 channels ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int X = 2 * (v0 + r) + px;
+        if (X >= a.W) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int Y = 2 * (u0 + wn * TN + j) + py;
+            if (Y >= a.H) continue;
+            const long pbase = (((long)b * a.H + Y) * a.W + X) * a.K;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = mt * BM + wm * 32 + 8 * g + 4 * h;
+                if (m >= a.K) continue;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[c][j][4 * g + k];
+                if (a.act) {
+                    const uint2 mk = *reinterpret_cast<const uint2*>(a.act + pbase + m);
+                    if (!((mk.x & 0x7FFFu) && !(mk.x & 0x8000u))) v[0] *= a.slope;
+                    if (!((mk.x >> 16) & 0x7FFFu) || (mk.x >> 31)) v[1] *= a.slope;
+                    if (!((mk.y & 0x7FFFu) && !(mk.y & 0x8000u))) v[2] *= a.slope;
+                    if (!((mk.y >> 16) & 0x7FFFu) || (mk.y >> 31)) v[3] *= a.slope;
+                }
+                uint2 o;
+                o.x = gd_pack_bf2(v[0], v[1]);
+                o.y = gd_pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(a.dx + pbase + m) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator image in ws (gd_conv3x3_ws_bytes(M, K) bytes with
-// (M, K) = (Cout, Cin) for the forward operator, (Cin, Cout) for transposed != 0 = the data-gradient operator)
+// (M, K) = (Cout, Cin) for the forward operator (transposed = 0, stride 1 or 2), (Cin, Cout) for transposed = 1 (the
+// stride-1 data-gradient operator: taps flipped) and transposed = 2 (the stride-2 data-gradient operator of
+// gd_conv3x3_nhwc_s2_dgrad: taps as stored, 64-row tiles)
 extern "C" int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int transposed, void* ws, size_t ws_bytes,
                                     void* stream) {
-    GD_CHECK_ARG(w && ws && Cout > 0 && Cin > 0, "gd_conv3x3_nhwc_pack: bad arguments");
+    GD_CHECK_ARG(w && ws && Cout > 0 && Cin > 0 && transposed >= 0 && transposed <= 2, "gd_conv3x3_nhwc_pack: bad arguments");
     const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
     GD_CHECK_ARG(ws_bytes >= gd_conv3x3_ws_bytes(M, K), "gd_conv3x3_nhwc_pack: workspace too small");
-    const int bm = pick_bm(M, K);
+    const int bm = transposed == 2 ? 64 : pick_bm(M, K);
     const int mtiles = (M + bm - 1) / bm, nchunks = (K + CK - 1) / CK;
     const long total = (long)mtiles * nchunks * 9 * bm * CK;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     const long sm = transposed ? 9 : (long)Cin * 9, sc = transposed ? (long)Cin * 9 : 9;
     hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, sm, sc, 1L, M, K,
-                       transposed ? 1 : 0, bm, nchunks, (unsigned short*)ws, total);
+                       transposed == 1 ? 1 : 0, bm, nchunks, (unsigned short*)ws, total);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias, const void* mask, const void* res,
+                            void* y, int B, int H, int W, int K, int M, int stride, int act, float slope, void* stream) {
+    NhwcConvArgs a;
+    a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
+    a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
+    a.H = H; a.W = W; a.K = K; a.M = M; a.act = act; a.slope = slope;
+    a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+    const int bm = pick_bm(M, K);
+    const int mtiles = (M + bm - 1) / bm;
+    a.nchunks = (K + CK - 1) / CK;
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    const int th = stride == 1 ? 8 : 4;
+    const int tiles_y = (a.Ho + th - 1) / th;
+    dim3 grid(a.tiles_x * tiles_y, mtiles, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 1>), grid, dim3(256), 0, s, a);
+    } else {
+        if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 2>), grid, dim3(256), 0, s, a);
+    }
     GD_LAUNCH_CHECK();
     return 0;
 }
@@ -460,18 +650,38 @@ extern "C" int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bi
     GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0,
                  "gd_conv3x3_nhwc: channel counts must be multiples of 8");
     GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc: image too large");
-    NhwcConvArgs a;
-    a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
-    a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
-    a.H = H; a.W = W; a.K = K; a.M = M; a.relu = relu;
-    const int bm = pick_bm(M, K);
-    const int mtiles = (M + bm - 1) / bm;
-    a.nchunks = (K + CK - 1) / CK;
-    a.tiles_x = (W + TW - 1) / TW;
-    const int tiles_y = (H + 7) / 8;
-    dim3 grid(a.tiles_x * tiles_y, mtiles, B);
-    if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    return nhwc_conv_launch(x, wpack, bias, mask, res, y, B, H, W, K, M, 1, relu ? 1 : 0, 0.f, stream);
+}
+
+// stride 2 / pad 1 forward: x (B, H, W, K) bf16 -> y (B, (H-1)/2+1, (W-1)/2+1, M) bf16, + bias, act 0 none / 1 ReLU /
+// 2 LeakyReLU(slope).  wpack = gd_conv3x3_nhwc_pack(transposed = 0).
+extern "C" int gd_conv3x3_nhwc_s2(const void* x, const void* wpack, const float* bias, void* y, int B, int H, int W, int K,
+                                  int M, int act, float slope, void* stream) {
+    GD_CHECK_ARG(x && wpack && y, "gd_conv3x3_nhwc_s2: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0 && act >= 0 && act <= 2,
+                 "gd_conv3x3_nhwc_s2: channel counts must be multiples of 8, act in 0..2");
+    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc_s2: image too large");
+    return nhwc_conv_launch(x, wpack, bias, nullptr, nullptr, y, B, H, W, K, M, 2, act, slope, stream);
+}
+
+// data gradient of gd_conv3x3_nhwc_s2: dy (B, Ho, Wo, M) bf16 -> dx (B, H, W, K) bf16, optionally times
+// LeakyReLU'(act_out) with act_out (B, H, W, K) the activation output this conv consumed.
+// wpack_t = gd_conv3x3_nhwc_pack(transposed = 2).
+extern "C" int gd_conv3x3_nhwc_s2_dgrad(const void* dy, const void* wpack_t, const void* act_out, float slope, void* dx,
+                                        int B, int H, int W, int K, int M, void* stream) {
+    GD_CHECK_ARG(dy && wpack_t && dx, "gd_conv3x3_nhwc_s2_dgrad: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0,
+                 "gd_conv3x3_nhwc_s2_dgrad: channel counts must be multiples of 8");
+    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc_s2_dgrad: image too large");
+    NhwcDgrad2Args a;
+    a.dy = (const unsigned short*)dy; a.wp = (const unsigned short*)wpack_t; a.act = (const unsigned short*)act_out;
+    a.dx = (unsigned short*)dx; a.H = H; a.W = W; a.K = K; a.M = M; a.slope = slope;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.nchunks = (M + CK - 1) / CK;
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    const int tiles_y = (a.Ho + 3) / 4;
+    dim3 grid(a.tiles_x * tiles_y, (K + 63) / 64, B);
+    hipLaunchKernelGGL(conv3x3_nhwc_dgrad2_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     GD_LAUNCH_CHECK();
     return 0;
 }
@@ -682,7 +892,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
                                 const void* x_nhwc16, int x_ld, const float* in_scale, const float* in_shift, int in_relu,
                                 int B, int Cout, int Cin, int H, int W, int stride, float* dw, void* stream) {
-    GD_CHECK_ARG(dy && x && dw, "gd_conv3x3_wgrad: null pointer");
+    GD_CHECK_ARG((dy || dy_bf16) && (x || x_nhwc16) && dw, "gd_conv3x3_wgrad: null pointer");
     GD_CHECK_ARG(!x_nhwc16 || (!in_scale && x_ld >= Cin && x_ld % 8 == 0),
                  "gd_conv3x3_wgrad: the pixel-major bf16 x needs x_ld >= Cin, x_ld % 8 == 0 and no input transform");
     GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gd_conv3x3_wgrad: bad sizes");

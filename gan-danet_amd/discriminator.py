@@ -24,9 +24,14 @@ class Discriminator1(nn.Module):
         self.activation = LeakyReLU(negative_slope=0.2, inplace=True)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            x = conv(x, ACT_LEAKY)
-        x = x.flatten(1)
+        convs = (self.conv1, self.conv2, self.conv3, self.conv4)
+        if ops.disc1_trunk_eligible(x, [c.weight for c in convs]):
+            # one node on pixel-major bf16 activations (ops.Disc1TrunkFn): forward, data and weight gradients
+            x = ops.Disc1TrunkFn.apply(x, *[t for c in convs for t in (c.weight, c.bias)])
+        else:
+            for conv in convs:
+                x = conv(x, ACT_LEAKY)
+            x = x.flatten(1)
         x = self.fc1(x, ACT_LEAKY)
         return self.fc2(x)
 

@@ -782,7 +782,8 @@ def _bf(t: Tensor, name: str = "tensor") -> Tensor:
 
 
 def conv3x3_nhwc_pack(w: Tensor, transposed: bool) -> Tensor:
-    """w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator (forward, or the data-gradient operator when transposed)"""
+    """w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator (transposed: 0 forward, 1 stride-1 data gradient, 2 stride-2
+    data gradient)"""
     _dense(w, "conv weight")
     Cout, Cin = w.shape[0], w.shape[1]
     M, Kc = (Cin, Cout) if transposed else (Cout, Cin)
@@ -806,6 +807,116 @@ def conv3x3_nhwc(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, relu:
         L.check(lib().gd_conv3x3_nhwc(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(mask), _ptr(res), _ptr(y), B, H, W, Kc, M,
                                       int(relu), _stream()), "gd_conv3x3_nhwc")
     return y
+
+
+# ---- Discriminator1 on pixel-major bf16 (discriminator.py:57-77) ------------------------------------------------------
+def _half_up(n: int) -> int:
+    return (n - 1) // 2 + 1
+
+
+def disc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], slope: float) -> Tensor:
+    """conv1: fp32 NCHW image -> LeakyReLU(conv3x3 s2 p1 + bias) as (B, Ho, Wo, Co) bf16"""
+    _dense(img, "stem image"), _dense(w, "stem weight")
+    B, Ci, H, W = img.shape
+    Co = w.shape[0]
+    if w.shape[1] != Ci:
+        raise L.GandanetError(f"disc_stem_fwd: weight {tuple(w.shape)} does not match image {tuple(img.shape)}")
+    y = torch.empty(B, _half_up(H), _half_up(W), Co, device=img.device, dtype=torch.bfloat16)
+    L.check(lib().gd_disc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, float(slope), _ptr(y), _stream()),
+            "gd_disc_stem_fwd")
+    return y
+
+
+def disc_stem_wgrad(g: Tensor, img: Tensor, want_bias: bool = True):
+    """(dw (Co, Ci, 3, 3), db (Co) or None) of conv1 from the pre-activation gradient g (B, Ho, Wo, Co) bf16"""
+    _bf(g, "stem gradient"), _dense(img, "stem image")
+    B, Ci, H, W = img.shape
+    Co = g.shape[3]
+    if g.shape[:3] != (B, _half_up(H), _half_up(W)):
+        raise L.GandanetError(f"disc_stem_wgrad: gradient {tuple(g.shape)} does not match image {tuple(img.shape)}")
+    dw = torch.empty(Co, Ci, 3, 3, device=g.device, dtype=torch.float32)
+    db = torch.empty(Co, device=g.device, dtype=torch.float32) if want_bias else None
+    L.check(lib().gd_disc_stem_wgrad(_ptr(g), _ptr(img), B, Ci, H, W, Co, _ptr(dw), _ptr(db), _stream()), "gd_disc_stem_wgrad")
+    return dw, db
+
+
+def disc_stem_dgrad(g: Tensor, w: Tensor, H: int, W: int) -> Tensor:
+    _bf(g, "stem gradient"), _dense(w, "stem weight")
+    B, Ho, Wo, Co = g.shape
+    Ci = w.shape[1]
+    if (Ho, Wo) != (_half_up(H), _half_up(W)):
+        raise L.GandanetError(f"disc_stem_dgrad: gradient {tuple(g.shape)} does not match a {H} x {W} image")
+    dimg = torch.empty(B, Ci, H, W, device=g.device, dtype=torch.float32)
+    L.check(lib().gd_disc_stem_dgrad(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), _stream()), "gd_disc_stem_dgrad")
+    return dimg
+
+
+def conv3x3_nhwc_s2(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, act: int, slope: float = 0.2) -> Tensor:
+    """x (B, H, W, K) bf16 -> act(conv3x3 s2 p1 + bias) (B, Ho, Wo, M) bf16; act 0 none / 1 ReLU / 2 LeakyReLU(slope)"""
+    _bf(x, "nhwc conv input")
+    B, H, W, Kc = x.shape
+    y = torch.empty(B, _half_up(H), _half_up(W), M, device=x.device, dtype=torch.bfloat16)
+    with _Bracket("conv3x3_nhwc_s2", 2.0 * 9 * Kc * M * y.shape[1] * y.shape[2] * B):
+        L.check(lib().gd_conv3x3_nhwc_s2(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(y), B, H, W, Kc, M, int(act), float(slope),
+                                         _stream()), "gd_conv3x3_nhwc_s2")
+    return y
+
+
+def conv3x3_nhwc_s2_dgrad(dy: Tensor, wpack_t: Tensor, act_out: Tensor, slope: float = 0.2) -> Tensor:
+    """dy (B, Ho, Wo, M) bf16 -> dx (B, H, W, K) bf16 = convT(dy) * LeakyReLU'(act_out); shape taken from act_out"""
+    _bf(dy, "nhwc conv gradient"), _bf(act_out, "activation output")
+    B, H, W, Kc = act_out.shape
+    M = dy.shape[3]
+    if dy.shape[:3] != (B, _half_up(H), _half_up(W)):
+        raise L.GandanetError(f"conv3x3_nhwc_s2_dgrad: dy {tuple(dy.shape)} does not match input {tuple(act_out.shape)}")
+    dx = torch.empty_like(act_out)
+    with _Bracket("conv3x3_nhwc_s2_dgrad", 2.0 * 9 * Kc * M * dy.shape[1] * dy.shape[2] * B):
+        L.check(lib().gd_conv3x3_nhwc_s2_dgrad(_ptr(dy), _ptr(wpack_t), _ptr(act_out), float(slope), _ptr(dx), B, H, W, Kc, M,
+                                               _stream()), "gd_conv3x3_nhwc_s2_dgrad")
+    return dx
+
+
+def nhwc_flatten_fwd(y: Tensor) -> Tensor:
+    """(B, h, w, C) bf16 -> (B, C*h*w) fp32 in the (c, h, w) order of NCHW .flatten(1)"""
+    _bf(y, "flatten input")
+    B, H, W, Cc = y.shape
+    f = torch.empty(B, Cc * H * W, device=y.device, dtype=torch.float32)
+    L.check(lib().gd_nhwc_flatten_fwd(_ptr(y), B, H * W, Cc, _ptr(f), _stream()), "gd_nhwc_flatten_fwd")
+    return f
+
+
+def nhwc_flatten_bwd(df: Tensor, y: Tensor, slope: float) -> Tensor:
+    _bf(y, "flatten input"), _dense(df, "flatten gradient")
+    B, H, W, Cc = y.shape
+    if df.numel() != y.numel():
+        raise L.GandanetError(f"nhwc_flatten_bwd: gradient {tuple(df.shape)} does not match {tuple(y.shape)}")
+    g = torch.empty_like(y)
+    L.check(lib().gd_nhwc_flatten_bwd(_ptr(df), _ptr(y), float(slope), B, H * W, Cc, _ptr(g), _stream()), "gd_nhwc_flatten_bwd")
+    return g
+
+
+def nhwc_to_nchw16(g: Tensor, want_sum: bool):
+    """(B, h, w, C) bf16 -> ((B, C, h, w) bf16, per-channel sums (C) fp32 or None)"""
+    _bf(g, "nhwc gradient")
+    B, H, W, Cc = g.shape
+    gt = torch.empty(B, Cc, H, W, device=g.device, dtype=torch.bfloat16)
+    cs = torch.empty(Cc, device=g.device, dtype=torch.float32) if want_sum else None
+    L.check(lib().gd_nhwc_to_nchw16(_ptr(g), B, H * W, Cc, _ptr(gt), _ptr(cs), _stream()), "gd_nhwc_to_nchw16")
+    return gt, cs
+
+
+def conv3x3_wgrad_nhwc(g: Tensor, x: Tensor, stride: int, want_bias: bool):
+    """Weight (and bias) gradient of a 3x3 / pad 1 conv whose input x (B, H, W, Cin) and output gradient g
+    (B, Ho, Wo, Cout) are pixel-major bf16: g goes channel-major once (fused with the bias sums), x is staged as is."""
+    _bf(g, "nhwc gradient"), _bf(x, "nhwc input")
+    B, H, W, Cin = x.shape
+    Cout = g.shape[3]
+    gt, db = nhwc_to_nchw16(g, want_bias)
+    dw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+    with _ConvBracket("wgrad_nhwc", 3, stride, Cin, Cout, g.shape[1], g.shape[2], B):
+        L.check(lib().gd_conv3x3_wgrad(None, 0, _ptr(gt), None, 0, _ptr(x), Cin, None, None, 0, B, Cout, Cin, H, W, stride,
+                                       _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+    return dw, db
 
 
 def nhwc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:

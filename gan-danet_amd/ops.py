@@ -36,6 +36,58 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 # =====================================================================================================
+# Discriminator1 conv trunk on pixel-major bf16      discriminator.py:60-63, 66-72
+# =====================================================================================================
+DISC_NHWC = os.environ.get("GD_DISC_NHWC", "1") != "0"
+
+
+def disc1_trunk_eligible(x: torch.Tensor, ws) -> bool:
+    """16-bit operand mode, non-deterministic mode (the bias sums and weight gradients use atomics), the reference's
+    channel ladder (.. -> 64 -> .. multiples of 8), at most 4 image channels"""
+    return (DISC_NHWC and config.precision != "fp32" and not K.DETERMINISTIC and x.dim() == 4 and x.shape[1] <= 4
+            and ws[0].shape[0] == 64 and all(w.shape[0] % 8 == 0 and w.shape[2:] == (3, 3) for w in ws))
+
+
+class Disc1TrunkFn(Function):
+    """conv1..conv4 (3x3, stride 2, pad 1, + bias + LeakyReLU(0.2)) and ``x.flatten(1)`` as ONE autograd node on
+    pixel-major bf16 activations.  The fp32-NCHW path rounds every conv input to bf16 while staging it, so storing the
+    activations in bf16 changes no product; what changes is the traffic (2 bytes per element, 16-byte patch copies) and
+    the data gradient, which runs by input-pixel parity instead of as four zero-skipping generic launches."""
+
+    SLOPE = 0.2
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4):
+        x = _c(x)
+        ws, bs = (w1, w2, w3, w4), (b1, b2, b3, b4)
+        acts = [K.disc_stem_fwd(x, _c(w1), b1, Disc1TrunkFn.SLOPE)]
+        for w, b in zip(ws[1:], bs[1:]):
+            acts.append(K.conv3x3_nhwc_s2(acts[-1], K.conv3x3_nhwc_pack(_c(w), 0), b, w.shape[0], 2, Disc1TrunkFn.SLOPE))
+        ctx.x, ctx.acts, ctx.ws = x, acts, ws
+        ctx.has_bias = tuple(b is not None for b in bs)
+        return K.nhwc_flatten_fwd(acts[-1])
+
+    @staticmethod
+    def backward(ctx, df):
+        x, acts, ws = ctx.x, ctx.acts, ctx.ws
+        need = ctx.needs_input_grad
+        grads = [None] * 9
+        g = K.nhwc_flatten_bwd(_c(df), acts[3], Disc1TrunkFn.SLOPE)          # w.r.t. conv4's pre-activation
+        for l in (3, 2, 1):
+            if need[1 + 2 * l] or need[2 + 2 * l]:
+                dw, db = K.conv3x3_wgrad_nhwc(g, acts[l - 1], 2, ctx.has_bias[l] and need[2 + 2 * l])
+                grads[1 + 2 * l], grads[2 + 2 * l] = (dw if need[1 + 2 * l] else None), db
+            g = K.conv3x3_nhwc_s2_dgrad(g, K.conv3x3_nhwc_pack(_c(ws[l]), 2), acts[l - 1], Disc1TrunkFn.SLOPE)
+        if need[1] or need[2]:
+            dw, db = K.disc_stem_wgrad(g, x, ctx.has_bias[0] and need[2])
+            grads[1], grads[2] = (dw if need[1] else None), db
+        if need[0]:
+            grads[0] = K.disc_stem_dgrad(g, _c(ws[0]), x.shape[2], x.shape[3])
+        ctx.acts = ctx.x = None
+        return tuple(grads)
+
+
+# =====================================================================================================
 # convolution (+ bias + activation)        nn.Conv2d  (generator.py / discriminator.py / VGG)
 # =====================================================================================================
 class Conv2dFn(Function):

@@ -250,8 +250,9 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
 /* ------------------------------------------------------------------------------------------
  * Pixel-major (NHWC) bf16 kernels for the frozen VGG19 feature stack of PerceptualLoss (losses.py:13-73;
  * torchvision vgg19.features[:21]).  Activations (B, H, W, C) bf16, C % 8 == 0.
- *   gd_conv3x3_nhwc_pack : w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator in ws; transposed != 0 packs the
- *                          data-gradient operator (channels swapped, taps flipped).  ws needs
+ *   gd_conv3x3_nhwc_pack : w (Cout, Cin, 3, 3) fp32 -> packed bf16 operator in ws; transposed = 1 packs the stride-1
+ *                          data-gradient operator (channels swapped, taps flipped), transposed = 2 the stride-2 one
+ *                          (channels swapped, taps as stored: gd_conv3x3_nhwc_s2_dgrad).  ws needs
  *                          gd_conv3x3_ws_bytes(M, K) bytes, (M, K) = (Cout, Cin) or (Cin, Cout).
  *   gd_conv3x3_nhwc      : y = [mask > 0] * act(conv3x3_p1(x) + bias) + res   (x: K channels, y/mask/res: M channels;
  *                          bias, mask, res may be NULL; mask = the ReLU output whose backward is being applied)
@@ -271,6 +272,36 @@ int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, voi
 int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx, void* stream);
 int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, void* stream);
 int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminator1 (discriminator.py:57-77: 4 x (conv3x3 stride 2 + LeakyReLU(0.2)) -> flatten -> fc1 -> fc2) on
+ * pixel-major bf16 activations.  Ho = (H-1)/2+1, Wo = (W-1)/2+1 throughout.
+ *   gd_disc_stem_fwd        : conv1 (discriminator.py:60) from the fp32 NCHW image (B, Ci <= 4, H, W):
+ *                             y (B, Ho, Wo, Co) bf16 = LeakyReLU(conv3x3_s2_p1(img) + bias)
+ *   gd_disc_stem_wgrad      : dw (Co, Ci, 3, 3), db (Co) fp32 (overwritten; db may be NULL) from the pre-activation
+ *                             gradient g (B, Ho, Wo, Co) bf16 and the image.  Co == 64.
+ *   gd_disc_stem_dgrad      : dimg (B, Ci, H, W) fp32 from g (the generator step differentiates through D)
+ *   gd_conv3x3_nhwc_s2      : conv2..4 (discriminator.py:61-63): x (B, H, W, K) -> y (B, Ho, Wo, M), + bias,
+ *                             act 0 none / 1 ReLU / 2 LeakyReLU(slope); wpack = gd_conv3x3_nhwc_pack(transposed = 0)
+ *   gd_conv3x3_nhwc_s2_dgrad: its data gradient, split by input-pixel parity (nine tap passes, no zero-stuffing):
+ *                             dx (B, H, W, K) = convT(dy) * LeakyReLU'(act_out), act_out (B, H, W, K) = the activation
+ *                             output this conv consumed (NULL: no mask); wpack_t = gd_conv3x3_nhwc_pack(transposed = 2)
+ *   gd_nhwc_flatten_fwd/bwd : x.flatten(1) (discriminator.py:72): y (B, HW, C) bf16 -> f (B, C*HW) fp32 in (c, h, w)
+ *                             order; backward g (B, HW, C) bf16 = df * LeakyReLU'(y)
+ *   gd_nhwc_to_nchw16       : g (B, HW, C) bf16 -> gt (B, C, HW) bf16 (the dy_bf16 operand of gd_conv3x3_wgrad) and,
+ *                             when csum != NULL, csum (C) fp32 = per-channel sums (the bias gradient; overwritten)
+ * ---------------------------------------------------------------------------------------- */
+int gd_disc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co, float slope,
+                     void* y, void* stream);
+int gd_disc_stem_wgrad(const void* g, const float* img, int B, int Ci, int H, int W, int Co, float* dw, float* db, void* stream);
+int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream);
+int gd_conv3x3_nhwc_s2(const void* x, const void* wpack, const float* bias, void* y, int B, int H, int W, int K, int M, int act,
+                       float slope, void* stream);
+int gd_conv3x3_nhwc_s2_dgrad(const void* dy, const void* wpack_t, const void* act_out, float slope, void* dx, int B, int H,
+                             int W, int K, int M, void* stream);
+int gd_nhwc_flatten_fwd(const void* y, int B, int HW, int C, float* f, void* stream);
+int gd_nhwc_flatten_bwd(const float* df, const void* y, float slope, int B, int HW, int C, void* g, void* stream);
+int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * PAM, fused (flash) form with 16-bit MFMA operands and fp32 softmax statistics (generator.py:115-122).

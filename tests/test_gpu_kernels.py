@@ -406,6 +406,62 @@ def test_conv3x3_nhwc_forward_and_data_gradient(gd, shape):
     assert_close(_nchw(dx), dxr, 1e-2, "nhwc dgrad with mask + res")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 32, 64, 128), (1, 128, 17, 35, 256), (2, 40, 9, 130, 24), (1, 256, 8, 8, 512),
+                                   (3, 8, 13, 11, 64)])
+def test_conv3x3_nhwc_stride2_forward_data_and_weight_gradient(gd, shape):
+    """Discriminator1 conv2..4 on pixel-major bf16 (gd_conv3x3_nhwc_s2, gd_conv3x3_nhwc_s2_dgrad by input parity,
+    gd_nhwc_to_nchw16 + gd_conv3x3_wgrad on the pixel-major input) against ATen on the same bf16-rounded operands;
+    odd sizes exercise every tile edge and the odd-row / odd-column tail of the parity split"""
+    _, K = _ops()
+    B, Cin, H, W, Cout = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = bf16_round(seeded((B, Cin, H, W), 231))
+    w = bf16_round(seeded((Cout, Cin, 3, 3), 232, 1.0 / math.sqrt(Cin * 9)))
+    bias = seeded((Cout,), 233, 0.1)
+    y = K.conv3x3_nhwc_s2(_nhwc(x), K.conv3x3_nhwc_pack(w.to(DEV), 0), bias.to(DEV), Cout, 2, 0.2)
+    yr = F.leaky_relu(F.conv2d(x, w, bias, stride=2, padding=1), 0.2)
+    assert tuple(y.shape) == (B, Ho, Wo, Cout)
+    assert_close(_nchw(y), yr, 1e-2, "nhwc s2 fwd")
+    dy = bf16_round(seeded((B, Cout, Ho, Wo), 234))
+    act = bf16_round(seeded((B, Cin, H, W), 235))           # stands for the LeakyReLU output feeding this conv
+    dx = K.conv3x3_nhwc_s2_dgrad(_nhwc(dy), K.conv3x3_nhwc_pack(w.to(DEV), 2), _nhwc(act), 0.2)
+    dxr = torch.nn.grad.conv2d_input((B, Cin, H, W), w, dy, stride=2, padding=1) * torch.where(act > 0, 1.0, 0.2)
+    assert_close(_nchw(dx), dxr, 1e-2, "nhwc s2 dgrad with LeakyReLU mask")
+    gt, cs = K.nhwc_to_nchw16(_nhwc(dy), True)
+    assert torch.equal(gt.float().cpu(), dy)
+    assert_close(cs, dy.sum((0, 2, 3)), 1e-4, "channel sums")
+    dw, db = K.conv3x3_wgrad_nhwc(_nhwc(dy), _nhwc(x), 2, True)
+    dwr = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, stride=2, padding=1)
+    assert_close(dw, dwr, 1e-3, "nhwc wgrad")
+    assert_close(db, dy.sum((0, 2, 3)), 1e-4, "bias gradient")
+
+
+@pytest.mark.parametrize("ci,hw", [(1, (24, 40)), (3, (37, 51)), (1, (64, 66))])
+def test_disc_stem_flatten_kernels(gd, ci, hw):
+    """Discriminator1 conv1 from the fp32 image (gd_disc_stem_fwd / _wgrad / _dgrad, fp32 FMAs) and x.flatten(1)"""
+    _, K = _ops()
+    B, (H, W), Co = 2, hw, 64
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    img = seeded((B, ci, H, W), 241)
+    w = seeded((Co, ci, 3, 3), 242, 0.3)
+    bias = seeded((Co,), 243, 0.1)
+    a = K.disc_stem_fwd(img.to(DEV), w.to(DEV), bias.to(DEV), 0.2)
+    ar = F.leaky_relu(F.conv2d(img, w, bias, stride=2, padding=1), 0.2)
+    assert_close(_nchw(a), ar, 1e-2, "stem fwd")
+    g = bf16_round(seeded((B, Co, Ho, Wo), 244))
+    dw, db = K.disc_stem_wgrad(_nhwc(g), img.to(DEV))
+    assert_close(dw, torch.nn.grad.conv2d_weight(img, (Co, ci, 3, 3), g, stride=2, padding=1), 1e-4, "stem wgrad")
+    assert_close(db, g.sum((0, 2, 3)), 1e-4, "stem bias gradient")
+    dimg = K.disc_stem_dgrad(_nhwc(g), w.to(DEV), H, W)
+    assert_close(dimg, torch.nn.grad.conv2d_input((B, ci, H, W), w, g, stride=2, padding=1), 1e-4, "stem dgrad")
+    f = K.nhwc_flatten_fwd(a)
+    assert torch.equal(f.cpu(), _nchw(a).flatten(1))
+    df = seeded(tuple(f.shape), 245)
+    gb = K.nhwc_flatten_bwd(df.to(DEV), a, 0.2)
+    gr = bf16_round(df.view(B, Co, Ho, Wo) * torch.where(_nchw(a) > 0, 1.0, 0.2))
+    assert torch.equal(_nchw(gb), gr)
+
+
 @pytest.mark.parametrize("ci", [1, 3])
 def test_nhwc_stem_pool_l1(gd, ci):
     _, K = _ops()
