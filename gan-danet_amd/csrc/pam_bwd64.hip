@@ -99,6 +99,30 @@ __device__ __forceinline__ bf16x8_t tr_frag(const s16x4_t& lo, const s16x4_t& hi
     const bf16x8_t f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return f;
 }
+// plain 16-byte LDS reads issued / awaited by hand (same contract as tr_issue / tr_wait): the compiler sinks its own
+// ds_read next to the first use when registers are tight, which exposes the LDS latency in front of every MFMA pair
+template <int OFF>
+__device__ __forceinline__ bf16x8_t lds_issue128(unsigned int addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4_t lds_issue128f(unsigned int addr) {
+    f32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float lds_issue32f(unsigned int addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait128(bf16x8_t& f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
 template <int I> struct IC { static constexpr int value = I; };
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -106,6 +130,60 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(IC<I>{});
         static_for<I + 1, N>(f);
     }
+}
+
+// ---- VGPR-form MFMAs as inline asm (schedule variant bit 3) ----------------------------------------------------------
+// With one wave per SIMD the function's register budget is 512, so hipcc selects the AGPR form for EVERY MFMA: the S and
+// dP tiles, which only feed VALU code, then cost a v_accvgpr_write per accumulator-input register and a v_accvgpr_read
+// per result register (128 of the ~250 VALU instructions of a tile).  The asm forms keep those four tiles in VGPRs and
+// take the row constants straight from their registers as srcC.  The hazard recognizer does not look inside inline asm:
+// the consumers of a result are held back by mfma_pad() (a data dependency + the software wait states the ISA asks for
+// between an 8-pass XDL write and a VALU read of the same VGPR: 11).
+template <bool F16>
+__device__ __forceinline__ void mfma_v_first(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
+    if constexpr (F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+template <bool F16>
+__device__ __forceinline__ void mfma_v_zero(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {
+    if constexpr (F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+template <bool F16>
+__device__ __forceinline__ void mfma_v_acc(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {
+    if constexpr (F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+// orders the consumers of a, b behind this point (and, with NOPS, behind the wait states of the last MFMA into them)
+template <bool NOPS>
+__device__ __forceinline__ void mfma_pad(f32x16_t& a, f32x16_t& b) {
+    if constexpr (NOPS) asm("s_nop 10" : "+v"(a), "+v"(b));
+    else asm("" : "+v"(a), "+v"(b));
+}
+// The first two k-steps of two accumulators that start from the same srcC tile c, as ONE statement: the srcC of an
+// in-flight 32x32 MFMA must not be overwritten for 13 wait states (WAR), and the compiler -- which does not know that
+// the asm reads c late -- would recycle c's registers right behind a single-MFMA statement (seen: an LDS load and a
+// v_accvgpr_read landing in the row constants under the MFMAs that were still reading them).  Two further MFMAs
+// (>= 16 quad-cycles) separate the last read of c from the end of this statement.
+template <bool F16>
+__device__ __forceinline__ void mfma_v_first2x2(f32x16_t& d0, f32x16_t& d1, const f32x16_t& c, const bf16x8_t& a0,
+                                                const bf16x8_t& b00, const bf16x8_t& b10, const bf16x8_t& a1,
+                                                const bf16x8_t& b01, const bf16x8_t& b11) {
+    if constexpr (F16)
+        asm("v_mfma_f32_32x32x16_f16 %0, %3, %4, %2\n\tv_mfma_f32_32x32x16_f16 %1, %3, %5, %2\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %6, %7, %0\n\tv_mfma_f32_32x32x16_f16 %1, %6, %8, %1"
+            : "=&v"(d0), "=&v"(d1)
+            : "v"(c), "v"(a0), "v"(b00), "v"(b10), "v"(a1), "v"(b01), "v"(b11));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %2\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, %2\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, %6, %7, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %6, %8, %1"
+            : "=&v"(d0), "=&v"(d1)
+            : "v"(c), "v"(a0), "v"(b00), "v"(b10), "v"(a1), "v"(b01), "v"(b11));
+}
+template <bool NOPS>
+__device__ __forceinline__ void mfma_pad4(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) {
+    if constexpr (NOPS) asm("s_nop 10" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 template <int CT, bool F16, int VREG, bool ATOMIC, int ORDER = 0>
@@ -136,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     constexpr int AOPS = ATOMIC ? 4 : 1;           // VMEM operations of one dQ hand-over per wave
     // schedule variants (A/B switches, see the loop): bit 0 DQ_FIRST, bit 1 HANDOVER_MID, bit 2 DMA_LATE
     constexpr bool DQ_FIRST = (ORDER & 1) != 0, HANDOVER_MID = (ORDER & 2) != 0, DMA_LATE = (ORDER & 4) != 0;
+    constexpr bool VFORM = (ORDER & 8) != 0;        // S / dP / dQ-part tiles through VGPR-form asm MFMAs
     static_assert(!HANDOVER_MID || DQ_FIRST, "the mid-iteration hand-over follows the early dQ steps");
     static_assert(DCH % 64 == 0 && (OFF_X % 8) == 0 && (OFF_XQ % 8) == 0 && (OFF_V % 8) == 0, "LDS carve");
     static_assert((OFF_V + V_ELEMS) * 2 <= 163840, "LDS budget");
@@ -225,14 +304,17 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         for (int i = 0; i < PPW; ++i) pbase[i] += (long)t * padv[i];
     };
     // issue the DMA of the tile the pointers stand on into ring slot `slot`, then step to tile `t + 1` (wrapping)
+    long pwrap[PPW];                      // the step from the last tile back to tile 0 (select + add: no multiply per tile)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) pwrap[i] = -(long)(nqt - 1) * padv[i];
     auto dma_next = [&](int t, int slot) {
-        const long step = (t + 1 == nqt) ? -(long)(nqt - 1) : 1;
+        const bool wrap = t + 1 == nqt;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             unsigned short* dst = lds + slot * SLOT + pdst[i];           // wave-uniform piece base
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pbase[i] + voff[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            pbase[i] += step * padv[i];
+            pbase[i] += wrap ? pwrap[i] : padv[i];
         }
     };
 
@@ -295,6 +377,46 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     };
 
+    // VFORM: the same hand-over in two halves -- the exchange-buffer reads are requested at the top of the iteration
+    // (hand-issued: no wait next to them), the sums and the VMEM operations follow a few MFMA steps later
+    struct HqRegs {
+        float v[4][4];
+        f32x4_t q[4];
+    };
+    auto hq_issue = [&](HqRegs& hq, int buf) {
+        if constexpr (ATOMIC) {
+            const unsigned int a = lds_addr(xq_base + buf * XQ_BUF + (8 * wave + h) * QXLD + r);
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, k = i >> 2, w = i & 3;
+                hq.v[k][w] = lds_issue32f<(w * 32 * QXLD + 2 * k * QXLD) * 4>(a);
+            });
+        } else {
+            const unsigned int a = lds_addr(xq_base + buf * XQ_BUF + (8 * wave + (lane >> 3)) * QXLD + (lane & 7) * 4);
+            static_for<0, 4>([&](auto ic) {
+                constexpr int w = decltype(ic)::value;
+                hq.q[w] = lds_issue128f<w * 32 * QXLD * 4>(a);
+            });
+        }
+    };
+    auto hq_commit = [&](HqRegs& hq, int tq) {
+        if constexpr (ATOMIC) {
+            float* acc = reinterpret_cast<float*>(dq_out) + (nb + (long)tq * 32) * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                atomicAdd(acc + (8 * wave + 2 * k + h) * 32 + r, (hq.v[k][0] + hq.v[k][1]) + (hq.v[k][2] + hq.v[k][3]));
+        } else {
+            unsigned short* part = reinterpret_cast<unsigned short*>(dq_out) + (((long)b * (Npad / 256) + kb) * Npad + (long)tq * 32) * 32;
+            const int i = 8 * wave + (lane >> 3), d4 = (lane & 7) * 4;
+            const f32x4_t a = (hq.q[0] + hq.q[1]) + (hq.q[2] + hq.q[3]);
+            const u32x2_t o = {pack2<false>(a[0], a[1]), pack2<false>(a[2], a[3])};
+            *reinterpret_cast<u32x2_t*>(part + i * 32 + d4) = o;
+        }
+    };
+
+    // the key-side operands above are complete: said with the BUILTIN so that the compiler's own wait-count pass knows it
+    // (it cannot see a wait inside asm text and would otherwise put vmcnt(0) in front of their first use in the loop,
+    // draining the DMA ring and the dQ atomics every tile)
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     dma_seek(tcur);
     int tpf = tcur;                          // the tile the DMA pointers stand on
     dma_next(tpf, 0);
@@ -310,14 +432,6 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
         __builtin_amdgcn_s_barrier();
         const int slot = it % NSLOT;
-        // VMEM order per iteration (the vmcnt count above relies on it): DMA of tile it+2 into the slot of tile it-1
-        // (every wave is past its reads of it: it is past this barrier), THEN the dQ hand-over of tile it-1
-        if constexpr (!DMA_LATE) {
-            dma_next(tpf, (it + 2) % NSLOT);
-            tpf = next_tile(tpf);
-        }
-        if constexpr (!HANDOVER_MID) dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
-
         // every LDS address below = (ring slot base) + (per-lane offset fixed for the whole sweep) + (compile-time
         // immediate): the XOR swizzle of the dO image only touches the low two chunk bits, so it folds into the
         // per-lane part
@@ -331,7 +445,130 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         const unsigned short* do_tr_hi = dOs + off_trd_hi;
         const unsigned short* q_tr = Qs + off_trq;
 
+        // VFORM: the row constants and the Q rows are requested right behind the barrier, in front of the DMA issue
+        f32x4_t rc4[8];
+        bf16x8_t qa0, qa1;
+        HqRegs hq;
+        if constexpr (VFORM) {
+            const unsigned int a_rc = lds_addr(RC + 4 * h), a_qr = lds_addr(q_rows);
+            rc4[0] = lds_issue128f<0>(a_rc);
+            rc4[1] = lds_issue128f<32>(a_rc);
+            rc4[2] = lds_issue128f<64>(a_rc);
+            rc4[3] = lds_issue128f<96>(a_rc);
+            qa0 = lds_issue128<0>(a_qr);
+            qa1 = lds_issue128<32>(a_qr);
+            rc4[4] = lds_issue128f<128>(a_rc);
+            rc4[5] = lds_issue128f<160>(a_rc);
+            rc4[6] = lds_issue128f<192>(a_rc);
+            rc4[7] = lds_issue128f<224>(a_rc);
+        }
+        // VMEM order per iteration (the vmcnt count above relies on it): DMA of tile it+2 into the slot of tile it-1
+        // (every wave is past its reads of it: it is past this barrier), THEN the dQ hand-over of tile it-1
+        // (VFORM issues both from inside the dP phase, in this order, under its MFMAs)
+        if constexpr (!DMA_LATE && !VFORM) {
+            dma_next(tpf, (it + 2) % NSLOT);
+            tpf = next_tile(tpf);
+        }
+        if constexpr (!HANDOVER_MID && !VFORM) dq_handover((it + 1) & 1, tprev);    // buffer written in iteration it-1
+
         f32x16_t sacc[2], dpacc[2];
+        u32x4_t pw[2][2];                              // VFORM: P fragments, packed chunk by chunk under the dP MFMAs
+        if constexpr (VFORM) {
+            constexpr int DPD = 2;                         // dO row fragments in flight ahead of the MFMAs
+            const unsigned int a_de = lds_addr(do_rows_e), a_do = lds_addr(do_rows_o);
+            bf16x8_t dq_[DPD + 1];
+            auto do_issue = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                dq_[s % (DPD + 1)] = (s & 1) ? lds_issue128<(s >> 1) * 64>(a_do) : lds_issue128<(s >> 1) * 64>(a_de);
+            };
+            static_for<0, DPD>([&](auto sc) { do_issue(sc); });
+            asm volatile("s_waitcnt lgkmcnt(%10)"
+                         : "+v"(rc4[0]), "+v"(rc4[1]), "+v"(rc4[2]), "+v"(rc4[3]), "+v"(rc4[4]), "+v"(rc4[5]), "+v"(rc4[6]),
+                           "+v"(rc4[7]), "+v"(qa0), "+v"(qa1)
+                         : "n"(DPD)
+                         : "memory");
+            f32x16_t rcA, rcD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rcA[4 * g + e] = rc4[g][e];
+                    rcD[4 * g + e] = rc4[4 + g][e];
+                }
+            mfma_v_first2x2<F16>(sacc[0], sacc[1], rcA, qa0, kfB[0][0], kfB[1][0], qa1, kfB[0][1], kfB[1][1]);
+            if constexpr (DMA_LATE) {
+                dma_next(tpf, (it + 2) % NSLOT);
+                tpf = next_tile(tpf);
+            }
+            // dP = dO V^T - delta: 2 CT steps of two MFMAs; the dO row fragment of step s + 2 is requested before the
+            // MFMAs of step s, and the exp / pack of P (eight chunks of four elements) is written between the steps it
+            // should run under -- asm statements carry no latency for the scheduler, so the order here IS the schedule;
+            // mfma_tie() pins it (no instruction, only a dependency through both operands)
+            auto p_chunk = [&](auto cc) {          // P = exp2(S) and its 16-bit pack, four accumulator registers at a time
+                constexpr int c = decltype(cc)::value, k2 = c >> 2, q = c & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[k2][4 * q + e] = gd_exp2_fast(sacc[k2][4 * q + e]);
+                pw[k2][q >> 1][2 * (q & 1)] = pack2<F16>(sacc[k2][4 * q], sacc[k2][4 * q + 1]);
+                pw[k2][q >> 1][2 * (q & 1) + 1] = pack2<F16>(sacc[k2][4 * q + 2], sacc[k2][4 * q + 3]);
+            };
+            static_for<0, 2 * CT>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                auto v_frag = [&](int k2) {
+                    if (k2 < VREG) return vB[k2 < VREG ? k2 : 0][s];
+                    return *reinterpret_cast<const bf16x8_t*>(v_rows + (k2 - VREG) * 32 * DLD + s * 16);
+                };
+                if constexpr (s == 0) {
+                    // steps 0 and 1 go out together at s == 1 (mfma_v_first2x2); meanwhile, under the S MFMAs, the
+                    // exchange-buffer reads of the hand-over (buffer written in iteration it-1) and fragment 2 are requested
+                    hq_issue(hq, (it + 1) & 1);
+                    if constexpr (DPD < 2 * CT) do_issue(IC<DPD>{});
+                } else if constexpr (s == 1) {
+                    // fragments 0 and 1 landed: the reads behind them are fragment 2 (if any)
+                    // (behind them: the hand-over reads and fragment 2 -- more than the counter can express: 15 is stricter)
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(dq_[0]), "+v"(dq_[1]) : "n"(ATOMIC ? 15 : (DPD < 2 * CT ? 5 : 4)) : "memory");
+                    bf16x8_t v00, v10;
+                    if (0 < VREG) v00 = vB[0][0];
+                    else v00 = *reinterpret_cast<const bf16x8_t*>(v_rows + (0 - VREG) * 32 * DLD);
+                    if (1 < VREG) v10 = vB[VREG > 1 ? 1 : 0][0];
+                    else v10 = *reinterpret_cast<const bf16x8_t*>(v_rows + (1 - VREG) * 32 * DLD);
+                    mfma_v_first2x2<F16>(dpacc[0], dpacc[1], rcD, dq_[0], v00, v10, dq_[1], v_frag(0), v_frag(1));
+                    if constexpr (1 + DPD < 2 * CT) do_issue(IC<1 + DPD>{});     // into the ring slot of fragment 0
+                } else {
+                    if constexpr (s + DPD < 2 * CT) do_issue(IC<s + DPD>{});
+                    constexpr int behind = (2 * CT - 1 - s) < DPD ? (2 * CT - 1 - s) : DPD;   // reads issued after fragment s
+                    lds_wait128<behind>(dq_[s % (DPD + 1)]);
+                    const bf16x8_t da = dq_[s % (DPD + 1)];
+                    mfma_v_acc<F16>(dpacc[0], da, v_frag(0));
+                    mfma_v_acc<F16>(dpacc[1], da, v_frag(1));
+                }
+                // S is final four MFMAs (> 11 quad-cycles) behind its last write at s == 1: chunk c runs under step c + 1
+                if constexpr (s >= 1 && s <= 8) {
+                    mfma_pad4<false>(sacc[0], sacc[1], dpacc[0], dpacc[1]);
+                    p_chunk(IC<s - 1>{});
+                    mfma_pad4<false>(sacc[0], sacc[1], dpacc[0], dpacc[1]);
+                }
+                // DMA of tile it+2, then the hand-over's VMEM operations: the order the vmcnt count at the loop top relies on
+                if constexpr (s == (2 * CT > 2 ? 2 : 2 * CT - 1)) {
+                    dma_next(tpf, (it + 2) % NSLOT);
+                    tpf = next_tile(tpf);
+                }
+                // hand the exchange-buffer values to the compiler as soon as they are known to have landed: they are older
+                // than fragment 2, whose wait has just passed (CT == 1 has no fragment 2: waited for here)
+                if constexpr (s == (2 * CT > 2 ? 2 : 1)) {
+                    if constexpr (2 * CT <= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (ATOMIC)
+                        asm volatile("" : "+v"(hq.v[0][0]), "+v"(hq.v[0][1]), "+v"(hq.v[0][2]), "+v"(hq.v[0][3]), "+v"(hq.v[1][0]),
+                                          "+v"(hq.v[1][1]), "+v"(hq.v[1][2]), "+v"(hq.v[1][3]), "+v"(hq.v[2][0]), "+v"(hq.v[2][1]),
+                                          "+v"(hq.v[2][2]), "+v"(hq.v[2][3]), "+v"(hq.v[3][0]), "+v"(hq.v[3][1]), "+v"(hq.v[3][2]),
+                                          "+v"(hq.v[3][3]));
+                    else
+                        asm volatile("" : "+v"(hq.q[0]), "+v"(hq.q[1]), "+v"(hq.q[2]), "+v"(hq.q[3]));
+                }
+                if constexpr (s == (2 * CT > 4 ? 4 : 2 * CT - 1)) hq_commit(hq, tprev);
+            });
+            static_for<(2 * CT - 1 < 8 ? 2 * CT - 1 : 8), 8>(p_chunk);      // narrow C: the chunks no step was left for
+            mfma_pad<true>(dpacc[0], dpacc[1]);
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4_t a = *reinterpret_cast<const f32x4_t*>(RC + 8 * g + 4 * h);
@@ -367,13 +604,19 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 dpacc[k2] = mfma16<F16>(da, vb, dpacc[k2]);
             }
         }
+        }
         bf16x8_t pf[2][2], dsf[2][2];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
+            if constexpr (VFORM) {
+                pf[k2][0] = __builtin_bit_cast(bf16x8_t, pw[k2][0]);
+                pf[k2][1] = __builtin_bit_cast(bf16x8_t, pw[k2][1]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[k2][e] = gd_exp2_fast(sacc[k2][e]);   // P
-            pf[k2][0] = pack_frag<F16>(sacc[k2], 0);
-            pf[k2][1] = pack_frag<F16>(sacc[k2], 1);
+                for (int e = 0; e < 16; ++e) sacc[k2][e] = gd_exp2_fast(sacc[k2][e]);   // P
+                pf[k2][0] = pack_frag<F16>(sacc[k2], 0);
+                pf[k2][1] = pack_frag<F16>(sacc[k2], 1);
+            }
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -437,13 +680,15 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         // DQ_FIRST: the dQ^T steps (and the exchange-buffer write) go in front of the dV^T / dK^T steps, so that the
         // iteration ends on independent MFMAs instead of a dependent chain + an LDS write in front of the barrier
         auto step_id = [](int i) constexpr { return DQ_FIRST ? (i < 2 ? CT + 1 + i : i - 2) : i; };
-        issue(IC<step_id(0)>{});
+        // transpose reads run LA steps ahead of their MFMAs (2 measured equal to 1: the waits are not what stalls)
+        constexpr int LA = 1;
+        static_for<0, (LA < NSTEP ? LA : NSTEP)>([&](auto ic) { issue(IC<step_id(decltype(ic)::value)>{}); });
         static_for<0, NSTEP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int id = step_id(i);
-            if constexpr (i + 1 < NSTEP) issue(IC<step_id(i + 1)>{});
-            if constexpr (i + 1 < NSTEP) tr_wait<4>(fb[id]);
-            else tr_wait<0>(fb[id]);
+            if constexpr (i + LA < NSTEP) issue(IC<step_id(i + LA)>{});
+            constexpr int ahead = (NSTEP - 1 - i) < LA ? (NSTEP - 1 - i) : LA;      // steps whose reads are behind this one
+            tr_wait<4 * ahead>(fb[id]);
             compute(IC<id>{});
             if constexpr (id == CT + 2) {       // dQ^T part complete
                 xq_write();
@@ -486,13 +731,14 @@ template <int CT, bool F16, int VREG, bool ATOMIC>
 void launch_k64(dim3 grid, hipStream_t s, const unsigned short* q, const unsigned short* k, const unsigned short* kT,
                 const unsigned short* v, const unsigned short* dO, const float* rc, int Npad, float* dkn, float* dv,
                 void* dq_out) {
-    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out);
+    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC, 8>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out);
 }
 }  // namespace
 
 extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int nb, float* dqn, void* stream);   // pam.hip
 
-// bench tooling: schedule variant of the K64 kernel (0 = production) and V-in-registers count (0 = default)
+// bench tooling: schedule variant of the K64 kernel (0 = production = VGPR-form S / dP tiles with the hand-placed
+// dP phase, 1 = the compiler-scheduled AGPR-form loop it replaced) and V-in-registers count (0 = default)
 static int g_k64_order = 0, g_k64_vreg = 0;
 extern "C" void gd_pam_k64_variant(int order, int vreg) {
     g_k64_order = order;
@@ -538,8 +784,8 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
         if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
         else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
         break;
-        switch (g_k64_order) {
-            K64_ORD(1) K64_ORD(3) K64_ORD(4) K64_ORD(5)
+        switch (g_k64_order == 1 ? 0 : -1) {      // variant 1 = the compiler-scheduled AGPR-form loop (ORDER 0)
+            K64_ORD(0)
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD
