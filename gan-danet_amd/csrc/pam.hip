@@ -24,6 +24,7 @@
 //   of pam_bwd64.hip (64 keys per wave, one wave per SIMD, fp32 atomics or deterministic parts for dQ); the kernels
 //   here are its reproducible / scratch-free fallbacks (gd_pam_flash_bwd forms 2 and 3).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pam_common.h"
 #include "../../include/gandanet.h"
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                                                             const unsigned short* __restrict__ v, int N, int Npad, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ x,
                                                             long x_bs, float* __restrict__ out, long out_bs,
-                                                            float* __restrict__ o_attn, float* __restrict__ lse) {
+                                                            float* __restrict__ o_attn, float* __restrict__ lse,
+                                                            const float* __restrict__ k_sqmax) {
     constexpr int CP = CT * 32;
     constexpr int NSUB = KT / 32;                   // 32-key sub-tiles per staged tile
     constexpr int VROWCH = KT / 8 + 1;              // 16-byte chunks per V row (data + 1 pad)
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     const int nkt = (N + KT - 1) / KT;
 
     dma_tile(0, 0);
+    auto sweep = [&](auto nm) {
+    constexpr bool NOMAX = decltype(nm)::value;
     for (int t = 0; t < nkt; ++t) {
         // an LDS-DMA is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt wait followed by a
         // barrier; hipcc does not emit that wait for us inside the loop (checked in the .s), so it is explicit
@@ -157,14 +161,16 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                     if ((t * KT + sub * 32 + acc_row(e, h)) >= N) sacc[sub][e] = -1e30f;
         }
         float mloc = sacc[0][0];
+        if constexpr (!NOMAX) {
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, sacc[sub][e]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        }
         float lsum = 0.f;
         bf16x8_t pf[NSUB][2];     // P^T tile as the B operand of O^T += V P^T (accumulator-as-operand)
-        if (t == 0 || __any(mloc > 0.f)) {
+        if (!NOMAX && (t == 0 || __any(mloc > 0.f))) {
             // new maximum, rounded UP to the operand type (bf16 / fp16) so that it survives the trip through the Q fragment exactly
             const float want = m + (t == 0 ? mloc : fmaxf(mloc, 0.f));
             float m_new;
@@ -236,6 +242,28 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
             __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);   // MFMAs
         }
     }
+    };
+    // Softmax is shift-invariant: the running maximum only guards exp2 against overflow.  |s_ij| <= |q_i| |k_j|
+    // (Cauchy-Schwarz on the operands exactly as the MFMA sees them, q pre-scaled by log2 e), so when that bound stays
+    // inside the exponent range of the P operand type for every query of the wave, the whole sweep runs with m = 0:
+    // no row maximum, no cross-half shuffle, no test, no rescale branch (8 % of the kernel at the bench shape).
+    // k_sqmax[b] = max_j |k_j|^2 comes from gd_pam_key_sqnorm_max; NULL keeps the running maximum unconditionally.
+    bool nomax = false;
+    if (k_sqmax) {
+        float q2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float qv = F16 ? (float)__builtin_bit_cast(_Float16, (unsigned short)qf[s][e]) : gd_bf2f((unsigned short)qf[s][e]);
+                q2 = fmaf(qv, qv, q2);
+            }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float bound = sqrtf(q2 * k_sqmax[b]) * 1.0001f;
+        nomax = __all(bound <= (F16 ? 13.f : 60.f));
+    }
+    if (nomax) sweep(std::true_type{});
+    else sweep(std::false_type{});
 
     if (ONES) l = __shfl(o[CT - 1][15], r + 32, 64);   // channel Cp-1 = accumulator row 31: register 15 of lane half 1
     const int qi = q0 + r;
@@ -651,6 +679,30 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
     for (int e = 0; e < 16; ++e) dqn[((long)b * 32 + acc_row(e, h)) * Npad + qi] = dq[e];
 }
 
+// max_j |k_j|^2 over the keys of an image, on the packed operand kt (B, Npad, 32) (slot d = 31 holds 1.0: excluded)
+__global__ __launch_bounds__(256) void pam_key_sqnorm_max_kernel(const unsigned short* __restrict__ kt, int N, int Npad,
+                                                                int f16, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    float s2 = 0.f;
+    if (j < N) {
+        const u32x4_t* p = reinterpret_cast<const u32x4_t*>(kt + ((long)b * Npad + j) * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4_t w = p[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = f16 ? unpack_lo<true>(w[e]) : unpack_lo<false>(w[e]);
+                const float hi = f16 ? unpack_hi<true>(w[e]) : unpack_hi<false>(w[e]);
+                s2 = fmaf(lo, lo, s2);
+                if (c != 3 || e != 3) s2 = fmaf(hi, hi, s2);      // element 31 = the ones slot
+            }
+        }
+    }
+    s2 = gd_block_max(s2, red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(out + b), __builtin_bit_cast(int, s2));   // non-negative floats order as ints
+}
+
 }  // namespace
 
 #define PAM_DISPATCH_CT(CT_, CALL)                         \
@@ -666,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_bwd_dq_kernel(
 
 extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                                 int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out,
-                                long out_bs, float* o_attn, float* lse, void* stream) {
+                                long out_bs, float* o_attn, float* lse, const float* k_sqnorm_max, void* stream) {
     GD_CHECK_ARG(qt && kt && v && gamma && x && out && o_attn && lse, "gd_pam_flash_fwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
@@ -678,7 +730,7 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     // reads of THIS kernel (experiment, wrong numerics) changed nothing: it is not LDS-bandwidth bound.
     const dim3 grid(Npad / 256, B), block(512);
     hipStream_t s = (hipStream_t)stream;
-#define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse
+#define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse, k_sqnorm_max
     if (f16) {
         if (v_ones) {
             PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true, true>), grid, block, 0, s, PAM_FWD_ARGS));
@@ -691,6 +743,15 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
         PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, false, false>), grid, block, 0, s, PAM_FWD_ARGS));
     }
 #undef PAM_FWD_ARGS
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_pam_key_sqnorm_max(const void* kt, int B, int N, int Npad, int f16, float* out, void* stream) {
+    GD_CHECK_ARG(kt && out && B > 0 && B <= 65535 && N > 0 && Npad >= N, "gd_pam_key_sqnorm_max: bad arguments");
+    GD_CHECK_ARG(hipMemsetAsync(out, 0, (size_t)B * sizeof(float), (hipStream_t)stream) == hipSuccess, "gd_pam_key_sqnorm_max: memset failed");
+    hipLaunchKernelGGL(pam_key_sqnorm_max_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)kt, N, Npad, f16, out);
     GD_LAUNCH_CHECK();
     return 0;
 }

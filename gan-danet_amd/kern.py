@@ -725,13 +725,24 @@ def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
     return d_raw, delta
 
 
+PAM_NOMAX = os.environ.get("GD_PAM_NOMAX", "1") != "0"      # let the forward drop the running maximum where a bound allows
+
+
+def pam_key_sqnorm_max(kt: Tensor, N: int, f16: bool = False) -> Tensor:
+    """max_j |k_j|^2 per image of the packed keys kt (B, Npad, 32) (gd_pam_key_sqnorm_max)"""
+    B, Npad = kt.shape[0], kt.shape[1]
+    out = torch.empty(B, device=kt.device, dtype=torch.float32)
+    L.check(lib().gd_pam_key_sqnorm_max(_ptr(kt), B, N, Npad, int(f16), _ptr(out), _stream()), "gd_pam_key_sqnorm_max")
+    return out
+
+
 def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32, v_ones: bool = False,
-                  f16: bool = False):
+                  f16: bool = False, k_sqmax: Optional[Tensor] = None):
     # algorithmic (unpadded) work: 2 N^2 (r + C) per image (SURVEY.md 8d)
     with _Bracket("pam_flash_fwd", 2.0 * N * N * (r_alg + Cn) * B):
         L.check(lib().gd_pam_flash_fwd(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, int(v_ones), int(f16),
                                        _ptr(gamma), _ptr(x), _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse),
-                                       _stream()), "gd_pam_flash_fwd")
+                                       _ptr(k_sqmax), _stream()), "gd_pam_flash_fwd")
 
 
 # backward form (gandanet.h GD_PAM_BWD_*): GD_PAM_BWD=0 K64 + fp32 atomics for dQ (default), 1 K64 + bf16 parts

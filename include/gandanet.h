@@ -320,7 +320,12 @@ int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum
  * ---------------------------------------------------------------------------------------- */
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                      int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
-                     float* o_attn, float* lse, void* stream);
+                     float* o_attn, float* lse, const float* k_sqnorm_max, void* stream);
+/* k_sqnorm_max (B floats, or NULL): max_j |k_j|^2 of each image's packed keys.  Softmax is shift-invariant; when
+ * |q_i| * max_j |k_j| (in log2 units, q is pre-scaled) stays inside the exponent range of the P operand type for every
+ * query of a wave, that wave sweeps the keys without a running maximum (no per-tile max / test / rescale).  NULL: the
+ * running maximum is always kept.  out (B floats) is overwritten. */
+int gd_pam_key_sqnorm_max(const void* kt, int B, int N, int Npad, int f16, float* out, void* stream);
 /* backward: 16-bit inputs qt, kt as above (B,Npad,32); kn (B,32,Npad) perm16-ordered (row 31 is don't-care);
  * vt (B,Npad,Cp); dot (B,Npad,Cp) = gamma*dOut; lse, delta (B,N) fp32 (delta = gamma*rowsum(dOut.*O)).  All packs
  * zero padded (gd_pack_bf16 does).  Outputs fp32, channel-major, overwritten: dqn, dkn (B,32,Npad), dv (B,Cp,Npad)

@@ -138,6 +138,42 @@ def test_pam_online_softmax_rescale_branch(gd, c):
     assert_close(y, yo, 3e-2, "spiked key")
 
 
+@pytest.mark.parametrize("scale,expect_fast", [(0.5, True), (6.0, False)])
+@pytest.mark.parametrize("f16", [False, True])
+def test_pam_forward_without_running_max_and_its_fallback(gd, scale, expect_fast, f16):
+    """gd_pam_flash_fwd with k_sqnorm_max: when |q_i| max_j |k_j| (log2 units) fits the exponent range of the P operand
+    type the sweep keeps no running maximum (softmax is shift-invariant); otherwise the running-maximum sweep runs.  Both
+    against an fp64 softmax on the operand-rounded q, k, v; the fallback is additionally bitwise the kernel without the
+    bound (same code path), the fast path is not (P is rounded at another scale)."""
+    from gan_danet_amd import kern as K
+    B, C, r, N = 2, 56, 7, 700
+    Np, Cp = 768, 64
+    rnd = (lambda t: t.to(torch.float16).float()) if f16 else bf16_round
+    q, k = seeded((B, r, N), 301, scale), seeded((B, r, N), 302, scale)
+    v, x = seeded((B, C, N), 303), seeded((B, C, N), 304)
+    gamma = torch.full((1,), 0.7, device=DEV)
+    qd, kd, vd, xd = (t.to(DEV) for t in (q, k, v, x))
+    _, qt = K.pack_bf16(qd, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32), f16=f16)
+    _, kt = K.pack_bf16(kd, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=f16)
+    vn, _ = K.pack_bf16(vd, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=Cp - 1, f16=f16)
+    ksq = K.pam_key_sqnorm_max(kt, N, f16)
+    assert_close(ksq, (rnd(k) ** 2).sum(1).max(1).values, 1e-5, "max |k|^2")
+    res = []
+    for bound in (None, ksq):
+        out, o, lse = torch.empty_like(xd), torch.empty_like(xd), torch.empty(B, N, device=DEV)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, xd, out, o, lse, r_alg=r, v_ones=True, f16=f16, k_sqmax=bound)
+        res.append((out, o, lse))
+    e = torch.einsum("bdi,bdj->bij", rnd(q * K.LOG2E).double() / K.LOG2E, rnd(k).double())
+    p = torch.softmax(e, dim=2)
+    oref = torch.einsum("bcj,bij->bci", rnd(v).double(), p)
+    for out, o, lse in res:
+        assert_close(o, oref, 1e-2, "O")
+        assert_close(lse, torch.logsumexp(e, dim=2), 2e-3 if f16 else 1e-2, "lse")
+        assert_close(out, 0.7 * oref + x.double(), 1e-2, "out")
+    same = torch.equal(res[0][1], res[1][1])
+    assert same != expect_fast, f"fast path taken: {not same}, expected {expect_fast}"
+
+
 def test_danet_vs_reference_fixture(gd, golden_dir):
     from gan_danet_amd.generator import DANetAttention
     fx = load_golden(golden_dir, "danet_c64_16x16")

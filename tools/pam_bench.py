@@ -57,6 +57,9 @@ fl = 2.0 * N * N * (r + C) * B
 from gan_danet_amd import _lib as L  # noqa: E402
 
 timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0), "fwd", fl)
+ksq = K.pam_key_sqnorm_max(kt, N)
+timeit(lambda: K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=ones >= 0, k_sqmax=ksq),
+       "fwd, max-free", fl)
 d_raw, delta = K.chan_dot(do, o, gamma)
 forms = [int(f) for f in os.environ.get("PAM_BENCH_FORMS", "0,1,2,3").split(",")]
 names = {0: "bwd k64 atomic", 1: "bwd k64 parts", 2: "bwd k32 parts", 3: "bwd 2 kernels"}
