@@ -12,7 +12,7 @@ mkdir -p $OUT profiles
 COMMIT=$(cat .git_head 2>/dev/null || git rev-parse --short HEAD 2>/dev/null || echo unknown)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_under_profiler.log 2>&1
 python3 tools/profile_summary.py stats $OUT/stats --top 60 > profiles/${TAG}_bench_kernel_stats.txt
-tail -1 $OUT/bench_under_profiler.log > profiles/${TAG}_bench_under_profiler.json.log || true
+grep "^{" $OUT/bench_under_profiler.log | tail -1 > profiles/${TAG}_bench_under_profiler.json.log || true
 rocprofv3 -i tools/pmc_r02.txt --kernel-trace --output-format csv -d $OUT/pmc -- python3 tools/pam_bench.py --batch 2 --iters 1 > $OUT/pmc.log 2>&1
 { echo "rocprofv3 -i tools/pmc_r02.txt --kernel-trace --output-format csv -- python3 tools/pam_bench.py --batch 2 --iters 1"
   echo "(MI355X, commit $COMMIT; C=184, N=65536, B=2; per-dispatch means; SQ_* wave counters in quad-cycles summed over waves,"

@@ -37,7 +37,7 @@ def total(pred):
     return int(sum((2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024 for k, v in kern.items() if pred(k)))
 
 
-# the first backward form pam_bench runs is the default one (K64 + atomics): its kernels are pam_bwd_k64_kernel<.., true, 0>,
+# the first backward form pam_bench runs is the default one (K64 + atomics): its kernels are pam_bwd_k64_kernel<6, false, 2, true, ORDER>,
 # pam_rowconst_kernel, pam_dq_transpose_kernel (+ the hipMemset of the dQ accumulator, not a kernel)
 B, N, C, r = 32, 65536, 184, 23
 Np, Cp = N, 192
@@ -52,7 +52,7 @@ out = {
     "kernels_per_dispatch": kern,
     "traffic_bytes_per_launch": {
         "pam_flash_fwd": total(lambda k: k.startswith("pam_fwd_dma_kernel") and "false>" in k.replace(" ", "")),
-        "pam_flash_bwd": total(lambda k: (k.startswith("pam_bwd_k64_kernel") and k.replace(" ", "").endswith("false,2,true,0>"))
+        "pam_flash_bwd": total(lambda k: re.fullmatch(r"pam_bwd_k64_kernel<6,false,2,true,\d+>", k.replace(" ", "")) is not None
                                or k.startswith("pam_rowconst") or k.startswith("pam_dq_transpose")),
     },
     "algorithmic_bytes_per_launch": {"pam_flash_fwd": alg_fwd, "pam_flash_bwd": alg_bwd,
