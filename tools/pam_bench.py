@@ -22,8 +22,8 @@ B, C, N = a.batch, a.channels, a.tile * a.tile
 r = max(1, C // 8)
 Np, Cp = (N + 255) // 256 * 256, (C + 31) // 32 * 32
 g = torch.Generator(device=dev).manual_seed(0)
-q = torch.randn(B, r, N, device=dev, generator=g) * 0.5
-k = torch.randn(B, r, N, device=dev, generator=g) * 0.5
+q = torch.randn(B, r, N, device=dev, generator=g) * float(os.environ.get("PB_QK_SCALE", "0.5"))
+k = torch.randn(B, r, N, device=dev, generator=g) * float(os.environ.get("PB_QK_SCALE", "0.5"))
 v = torch.randn(B, C, N, device=dev, generator=g)
 x = torch.randn(B, C, N, device=dev, generator=g)
 do = torch.randn(B, C, N, device=dev, generator=g)
