@@ -141,6 +141,7 @@ SIGNATURES = {
     "gd_comm_destroy": (_i, []),
     "gd_pack_bf16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "gd_pack_16": (_i, [_p, _l, _i, _i, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "gd_pack_16_affine": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p]),
 }
 
 _lib = None

@@ -188,6 +188,90 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     }
 }
 
+// The same on 64 x 64 tiles with 16-byte accesses (float4 reads, 8 x 16-bit stores) for the aligned case (Cc % 4 == 0,
+// output leading dimensions % 8 == 0): the 32 x 32 kernel above moves 2-byte elements in 64-byte runs.  Optional per-row
+// affine + ReLU (row_scale / row_shift: the BatchNorm+ReLU prologue of a dense layer, applied while packing its input).
+__global__ __launch_bounds__(256) void pack16_tile64_kernel(const float* __restrict__ s, long s_bs, int R, int Cc,
+                                                           const float* __restrict__ scale, float scale_imm,
+                                                           const float* __restrict__ row_scale,
+                                                           const float* __restrict__ row_shift, int relu,
+                                                           unsigned short* __restrict__ plain, int Rp, int ldp,
+                                                           unsigned short* __restrict__ tr, int Ccp, int ldt, int perm16,
+                                                           int ones_row, int f16) {
+    constexpr int TLD = 72;                               // 144-byte rows: 16-byte aligned
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * TLD];
+    const int b = blockIdx.z;
+    const float* sp = s + (long)b * s_bs;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const float k = scale ? scale_imm * (*scale) : scale_imm;
+    auto cvt2 = [f16](float a, float bb) -> unsigned int {
+        if (f16) {
+            const unsigned int lo = __builtin_bit_cast(unsigned short, (_Float16)a), hi = __builtin_bit_cast(unsigned short, (_Float16)bb);
+            return lo | (hi << 16);
+        }
+        return gd_pack_bf2(a, bb);
+    };
+    {
+        const int cg = (tid & 15) * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int rl = (tid >> 4) + 16 * kk;
+            const int r = r0 + rl, c = c0 + cg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r == ones_row) {
+                v = make_float4(1.f, 1.f, 1.f, 1.f);
+            } else if (r < R && c < Cc) {                 // Cc % 4 == 0: a float4 is all in or all out
+                v = *reinterpret_cast<const float4*>(sp + (long)r * Cc + c);
+                float a = k, sh = 0.f;
+                if (row_scale) { a *= row_scale[r]; sh = row_shift[r]; }
+                v.x = fmaf(v.x, a, sh); v.y = fmaf(v.y, a, sh); v.z = fmaf(v.z, a, sh); v.w = fmaf(v.w, a, sh);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            uint2 w;
+            w.x = cvt2(v.x, v.y);
+            w.y = cvt2(v.z, v.w);
+            *reinterpret_cast<uint2*>(tile + rl * TLD + cg) = w;
+        }
+    }
+    __syncthreads();
+    if (plain) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int it = tid + 256 * kk;
+            const int rl = it >> 3, g = it & 7;
+            const int r = r0 + rl, c = c0 + 8 * g;
+            if (r < Rp && c < ldp) {
+                uint4 o;
+                if (perm16) {       // output positions [0-3, 4-7 | 8-11, 12-15] of a 16-group hold source columns [0-3, 8-11 | 4-7, 12-15]
+                    const int base = 16 * (g >> 1) + 4 * (g & 1);
+                    const uint2 lo = *reinterpret_cast<const uint2*>(tile + rl * TLD + base);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(tile + rl * TLD + base + 8);
+                    o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    o = *reinterpret_cast<const uint4*>(tile + rl * TLD + 8 * g);
+                }
+                *reinterpret_cast<uint4*>(plain + (long)b * Rp * ldp + (long)r * ldp + c) = o;
+            }
+        }
+    }
+    if (tr) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int it = tid + 256 * kk;
+            const int cl = it >> 3, rg = (it & 7) * 8;
+            const int c = c0 + cl, r = r0 + rg;
+            if (c < Ccp && r < ldt) {
+                unsigned int w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = (unsigned int)tile[(rg + 2 * j) * TLD + cl] | ((unsigned int)tile[(rg + 2 * j + 1) * TLD + cl] << 16);
+                *reinterpret_cast<uint4*>(tr + (long)b * Ccp * ldt + (long)c * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+}
+
 // ---- CustomDataset.apply_augmentation (datasets.py:181-208) as one gather -------------------------------------------
 // op word of a sample: bit 0 horizontal flip, bit 1 vertical flip, bits 2-3 number of 90-degree turns (torch.rot90,
 // dims [1, 2]), bit 4 additive noise.  The three geometric steps compose to one index map; tiles are square when
@@ -614,9 +698,39 @@ extern "C" int gd_pack_16(const float* s, long s_bs, int B, int R, int Cc, const
     if (plain) { rows = rows > Rp_plain ? rows : Rp_plain; cols = cols > ld_plain ? cols : ld_plain; }
     if (transposed) { rows = rows > ld_t ? rows : ld_t; cols = cols > Ccp_t ? cols : Ccp_t; }
     GD_CHECK_ARG(gd_cdiv(rows, 32) <= 65535, "gd_pack_16: too many rows");
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
-                       scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
-                       ld_t, perm16, ones_row, f16);
+    const bool aligned = Cc % 4 == 0 && s_bs % 4 == 0 && ((uintptr_t)s % 16) == 0 && (!plain || (ld_plain % 8 == 0 && (uintptr_t)plain % 16 == 0)) &&
+                         (!transposed || (ld_t % 8 == 0 && (uintptr_t)transposed % 16 == 0));
+    if (aligned)
+        hipLaunchKernelGGL(pack16_tile64_kernel, dim3(gd_cdiv(cols, 64), gd_cdiv(rows, 64), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
+                           scale_dev, scale_imm, (const float*)nullptr, (const float*)nullptr, 0, (unsigned short*)plain, Rp_plain,
+                           ld_plain, (unsigned short*)transposed, Ccp_t, ld_t, perm16, ones_row, f16);
+    else
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(gd_cdiv(cols, 32), gd_cdiv(rows, 32), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
+                           scale_dev, scale_imm, (unsigned short*)plain, Rp_plain, ld_plain, (unsigned short*)transposed, Ccp_t,
+                           ld_t, perm16, ones_row, f16);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+// pack with a per-row affine + ReLU applied first (row r: max(0, row_scale[r] * x + row_shift[r]) when relu, R entries each):
+// the BatchNorm + ReLU prologue of a dense layer, for the pixel-major bf16 copy its weight gradient reads.  Aligned case only
+// (Cc % 4 == 0, leading dimensions % 8 == 0).
+extern "C" int gd_pack_16_affine(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
+                                 int relu, void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t,
+                                 int f16, void* stream) {
+    GD_CHECK_ARG(s && (plain || transposed) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_16_affine: bad arguments");
+    GD_CHECK_ARG((row_scale == nullptr) == (row_shift == nullptr), "gd_pack_16_affine: row_scale / row_shift come together");
+    GD_CHECK_ARG(!plain || (Rp_plain >= R && ld_plain >= Cc), "gd_pack_16_affine: plain padding smaller than the data");
+    GD_CHECK_ARG(!transposed || (Ccp_t >= Cc && ld_t >= R), "gd_pack_16_affine: transposed padding smaller than the data");
+    GD_CHECK_ARG(Cc % 4 == 0 && s_bs % 4 == 0 && ((uintptr_t)s % 16) == 0 && (!plain || (ld_plain % 8 == 0 && (uintptr_t)plain % 16 == 0)) &&
+                     (!transposed || (ld_t % 8 == 0 && (uintptr_t)transposed % 16 == 0)),
+                 "gd_pack_16_affine: needs Cc % 4 == 0, leading dimensions % 8 == 0 and 16-byte aligned pointers");
+    int rows = R, cols = Cc;
+    if (plain) { rows = rows > Rp_plain ? rows : Rp_plain; cols = cols > ld_plain ? cols : ld_plain; }
+    if (transposed) { rows = rows > ld_t ? rows : ld_t; cols = cols > Ccp_t ? cols : Ccp_t; }
+    GD_CHECK_ARG(gd_cdiv(rows, 64) <= 65535, "gd_pack_16_affine: too many rows");
+    hipLaunchKernelGGL(pack16_tile64_kernel, dim3(gd_cdiv(cols, 64), gd_cdiv(rows, 64), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
+                       (const float*)nullptr, 1.f, row_scale, row_shift, relu, (unsigned short*)plain, Rp_plain, ld_plain,
+                       (unsigned short*)transposed, Ccp_t, ld_t, 0, -1, f16);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -395,6 +395,11 @@ int gd_pack_bf16(const float* s, long s_bs, int B, int R, int Cc, const float* s
 int gd_pack_16(const float* s, long s_bs, int B, int R, int Cc, const float* scale_dev, float scale_imm, void* plain,
                int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int perm16, int ones_row, int f16,
                void* stream);
+/* gd_pack_16 with a per-row affine + ReLU applied first (row r -> max(0, row_scale[r] x + row_shift[r]) when relu): the
+ * BatchNorm + ReLU prologue of a dense layer (generator.py:29-45), for the pixel-major bf16 copy of its input that
+ * gd_conv3x3_wgrad reads (x_nhwc16).  Aligned shapes only: Cc % 4 == 0, ld % 8 == 0. */
+int gd_pack_16_affine(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift, int relu,
+                      void* plain, int Rp_plain, int ld_plain, void* transposed, int Ccp_t, int ld_t, int f16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * RCCL communicator for hosts without torch.distributed (one process per GPU, one communicator per process; the
