@@ -107,6 +107,7 @@ SIGNATURES = {
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gd_conv3x3_nhwc_f32out": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p]),
     "gd_disc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _f, _p, _p]),
     "gd_disc_stem_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "gd_disc_stem_dgrad": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),

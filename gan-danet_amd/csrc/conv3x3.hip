@@ -267,6 +267,8 @@ struct NhwcConvArgs {
     const unsigned short* mask;   // (B, Ho, Wo, M) bf16 or null
     const unsigned short* res;    // (B, Ho, Wo, M) bf16 or null
     unsigned short* y;            // (B, Ho, Wo, M) bf16
+    float* y32;                   // alternative output: fp32 NCHW (B, M, Ho, Wo) with batch stride y32_bs (y unused then)
+    long y32_bs;
     int H, W, Ho, Wo, K, M, act, tiles_x, nchunks;   // act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
     float slope;
 };
@@ -427,6 +429,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
                         v[1] += gd_bf2f((unsigned short)(rr.x >> 16));
                         v[2] += gd_bf2f((unsigned short)(rr.y & 0xFFFFu));
                         v[3] += gd_bf2f((unsigned short)(rr.y >> 16));
+                    }
+                    if (a.y32) {
+                        // fp32 NCHW: for one channel the 32 lanes of a half-wave are 32 consecutive pixels (128-byte rows)
+                        float* yp = a.y32 + (long)b * a.y32_bs + (long)m * a.Ho * a.Wo + (long)oy * a.Wo + ox;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) yp[(long)k * a.Ho * a.Wo] = v[k];
+                        continue;
                     }
                     uint2 o;
                     o.x = gd_pack_bf2(v[0], v[1]);
@@ -619,8 +628,10 @@ extern "C" int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int trans
 }
 
 static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias, const void* mask, const void* res,
-                            void* y, int B, int H, int W, int K, int M, int stride, int act, float slope, void* stream) {
+                            void* y, int B, int H, int W, int K, int M, int stride, int act, float slope, void* stream,
+                            float* y32 = nullptr, long y32_bs = 0) {
     NhwcConvArgs a;
+    a.y32 = y32; a.y32_bs = y32_bs;
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
     a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
     a.H = H; a.W = W; a.K = K; a.M = M; a.act = act; a.slope = slope;
@@ -651,6 +662,19 @@ extern "C" int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bi
                  "gd_conv3x3_nhwc: channel counts must be multiples of 8");
     GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc: image too large");
     return nhwc_conv_launch(x, wpack, bias, mask, res, y, B, H, W, K, M, 1, relu ? 1 : 0, 0.f, stream);
+}
+
+// stride 1 with an fp32 NCHW result: x (B, H, W, K) bf16 pixel-major -> y32 (B, M, H, W) fp32 (batch stride y_bs elements),
+// + bias, act 0 / 1.  For the wide 3x3 convs of the generator (the 2C -> C fuse conv of DANetAttention, generator.py:108):
+// the caller packs the fp32 NCHW input pixel-major once (gd_pack_16, shared with gd_conv3x3_wgrad's x_nhwc16) and gets
+// the NHWC kernel's 16-byte patch staging; the data gradient is the same call on the packed dY with the transposed operator.
+extern "C" int gd_conv3x3_nhwc_f32out(const void* x, const void* wpack, const float* bias, float* y32, long y_bs, int B, int H,
+                                      int W, int K, int M, int relu, void* stream) {
+    GD_CHECK_ARG(x && wpack && y32, "gd_conv3x3_nhwc_f32out: null pointer");
+    GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 4 == 0 && y_bs >= (long)M * H * W,
+                 "gd_conv3x3_nhwc_f32out: K must be a multiple of 8, M of 4");
+    GD_CHECK_ARG((long)H * W * K < (1L << 31), "gd_conv3x3_nhwc_f32out: image too large");
+    return nhwc_conv_launch(x, wpack, bias, nullptr, nullptr, nullptr, B, H, W, K, M, 1, relu ? 1 : 0, 0.f, stream, y32, y_bs);
 }
 
 // stride 2 / pad 1 forward: x (B, H, W, K) bf16 -> y (B, (H-1)/2+1, (W-1)/2+1, M) bf16, + bias, act 0 none / 1 ReLU /

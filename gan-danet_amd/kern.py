@@ -820,6 +820,33 @@ def conv3x3_nhwc(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, relu:
     return y
 
 
+def conv3x3_nhwc_f32out(x16: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, H: int, W: int, relu: bool = False,
+                        out: Optional[Tensor] = None) -> Tensor:
+    """x16 (B, H*W, K) pixel-major bf16 (pack_bf16 transposed output) -> conv3x3 s1 p1 (+bias, ReLU) as (B, M, H, W) fp32"""
+    _bf(x16, "nhwc conv input")
+    B, HW, Kc = x16.shape
+    if HW != H * W:
+        raise L.GandanetError(f"conv3x3_nhwc_f32out: input {tuple(x16.shape)} is not a {H} x {W} image")
+    if out is None:
+        out = torch.empty(B, M, H, W, device=x16.device, dtype=torch.float32)
+    with _ConvBracket("nhwc_f32out", 3, 1, Kc, M, H, W, B):
+        L.check(lib().gd_conv3x3_nhwc_f32out(_ptr(x16), _ptr(wpack), _ptr(bias), _ptr(out), _bview(out, "conv out"), B, H, W, Kc,
+                                             M, int(relu), _stream()), "gd_conv3x3_nhwc_f32out")
+    return out
+
+
+def conv3x3_wgrad_packed(dy16: Tensor, x16: Tensor, H: int, W: int, stride: int = 1) -> Tensor:
+    """weight gradient from the two 16-bit copies: dy16 (B, Cout, Ho*Wo) channel-major, x16 (B, H*W, Cin) pixel-major"""
+    _bf(dy16, "dy16"), _bf(x16, "x16")
+    B, Cout = dy16.shape[0], dy16.shape[1]
+    Cin = x16.shape[2]
+    dw = torch.empty(Cout, Cin, 3, 3, device=dy16.device, dtype=torch.float32)
+    with _ConvBracket("wgrad_packed", 3, stride, Cin, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, B):
+        L.check(lib().gd_conv3x3_wgrad(None, 0, _ptr(dy16), None, 0, _ptr(x16), Cin, None, None, 0, B, Cout, Cin, H, W, stride,
+                                       _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+    return dw
+
+
 # ---- Discriminator1 on pixel-major bf16 (discriminator.py:57-77) ------------------------------------------------------
 def _half_up(n: int) -> int:
     return (n - 1) // 2 + 1

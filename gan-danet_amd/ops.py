@@ -90,13 +90,35 @@ class Disc1TrunkFn(Function):
 # =====================================================================================================
 # convolution (+ bias + activation)        nn.Conv2d  (generator.py / discriminator.py / VGG)
 # =====================================================================================================
+CONV_WIDE_NHWC = os.environ.get("GD_CONV_WIDE_NHWC", "1") != "0"
+
+
+def _wide3x3(x, w, stride, pad, act, prec) -> bool:
+    """wide 3x3 / stride 1 / pad 1 convs in 16-bit mode (the 2C -> C fuse conv of DANetAttention, generator.py:108, and the
+    C -> 64 conv behind the last block): run on a pixel-major bf16 copy of the input through the NHWC kernel"""
+    return (CONV_WIDE_NHWC and prec == L.PREC_BF16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and stride == 1
+            and pad == 1 and act in (ACT_NONE, ACT_RELU) and w.shape[1] >= 128 and w.shape[1] % 8 == 0 and w.shape[0] > 32
+            and w.shape[0] % 8 == 0 and (x.shape[2] * x.shape[3]) % 8 == 0)
+
+
 class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride: int, pad: int, act: int, prec=None):
         prec = _prec() if prec is None else prec
+        if _wide3x3(x, w, stride, pad, act, prec):
+            # one pixel-major bf16 copy of x serves the forward (16-byte patch staging, no gather / convert in the
+            # kernel) and the weight gradient; only that copy is kept for the backward
+            B, Cin, H, W = x.shape
+            _, x16 = K.pack_bf16(x, Cin, H * W, t_shape=(H * W, Cin))
+            y = K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(_c(w), 0), bias, w.shape[0], H, W, relu=act == ACT_RELU)
+            ctx.save_for_backward(x16, w, y if act != ACT_NONE else None)
+            ctx.cfg = (stride, pad, act, prec, bias is not None)
+            ctx.wide = (H, W)
+            return y
         y = K.conv2d_fwd(x, w, bias, stride, pad, prec, act=act)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, prec, bias is not None)
+        ctx.wide = None
         return y
 
     @staticmethod
@@ -107,6 +129,18 @@ class Conv2dFn(Function):
         if act != ACT_NONE:
             dy = K.act_bwd(y, dy, act)
         dx = dw = db = None
+        if ctx.wide is not None:
+            H, W = ctx.wide
+            B, Cout = dy.shape[0], dy.shape[1]
+            # dY once in both 16-bit layouts: channel-major for the weight gradient, pixel-major for the data gradient
+            dy16, dyt16 = K.pack_bf16(dy.view(B, Cout, H * W), Cout, H * W, plain_shape=(Cout, H * W), t_shape=(H * W, Cout))
+            if ctx.needs_input_grad[0]:
+                dx = K.conv3x3_nhwc_f32out(dyt16, K.conv3x3_nhwc_pack(_c(w), 1), None, w.shape[1], H, W)
+            if ctx.needs_input_grad[1]:
+                dw = K.conv3x3_wgrad_packed(dy16, x, H, W)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = K.channel_sum(dy)
+            return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad, prec)
         if ctx.needs_input_grad[1]:

@@ -265,6 +265,10 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
 int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int transposed, void* ws, size_t ws_bytes, void* stream);
 int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bias, const void* mask, const void* res, void* y, int B,
                     int H, int W, int K, int M, int relu, void* stream);
+/* the same kernel with an fp32 NCHW result (B, M, H, W), batch stride y_bs elements: wide 3x3 convs of the generator on a
+ * pixel-major bf16 copy of their input (gd_pack_16 transposed output, K = its leading dimension, zero padded) */
+int gd_conv3x3_nhwc_f32out(const void* x, const void* wpack, const float* bias, float* y32, long y_bs, int B, int H, int W, int K,
+                           int M, int relu, void* stream);
 int gd_nhwc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co, int relu,
                      void* y, void* stream);
 int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream);

@@ -74,6 +74,46 @@ def test_conv2d_fwd_bwd(gd, case, prec):
         assert_close(bg.grad, br.grad, 1e-4, "db")
 
 
+@pytest.mark.parametrize("shape", [(2, 136, 12, 20, 48, False, False), (1, 368, 16, 32, 184, False, False),
+                                   (2, 128, 9, 8, 40, True, True)])
+def test_wide_conv3x3_through_the_pixel_major_kernel(gd, shape):
+    """wide 3x3 / stride 1 / pad 1 convs in 16-bit mode (ops._wide3x3: DANetAttention's fuse conv, generator.py:108) run on
+    a pixel-major bf16 copy of x through the NHWC kernel with an fp32 NCHW result; forward, both gradients and the input
+    given as a channel slice of a wider buffer, against ATen on the bf16-rounded operands and against the fp32-NCHW
+    patch kernel (GD_CONV_WIDE_NHWC off), which rounds the same operands"""
+    ops, _ = _ops()
+    B, Cin, H, W, Cout, bias, relu = shape
+    assert ops._wide3x3(torch.empty(B, Cin, H, W), torch.empty(Cout, Cin, 3, 3), 1, 1, ops.ACT_NONE, ops.L.PREC_BF16)
+    wide = bf16_round(seeded((B, Cin + 8, H, W), 11))
+    x = wide[:, 4:4 + Cin]                                   # batch stride (Cin + 8) H W
+    w = bf16_round(seeded((Cout, Cin, 3, 3), 12, 1.0 / math.sqrt(Cin * 9)))
+    b = seeded((Cout,), 13, 0.1) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    yr = F.relu(yr) if relu else yr
+    go = bf16_round(seeded(tuple(yr.shape), 14))
+    yr.backward(go)
+    res = {}
+    for on in (True, False):
+        old = ops.CONV_WIDE_NHWC
+        ops.CONV_WIDE_NHWC = on
+        try:
+            wd = wide.to(DEV).requires_grad_(True)
+            wg = w.to(DEV).requires_grad_(True)
+            with gd.precision("bf16"):
+                y = ops.conv2d(wd[:, 4:4 + Cin], wg, b.to(DEV) if bias else None, 1, 1, ops.ACT_RELU if relu else ops.ACT_NONE)
+                y.backward(go.to(DEV))
+        finally:
+            ops.CONV_WIDE_NHWC = old
+        res[on] = (y.detach(), wd.grad[:, 4:4 + Cin], wg.grad)
+        assert_close(y, yr, BF16_TOL, "y")
+        assert_close(res[on][1], xr.grad, BF16_TOL, "dx", rell2)
+        assert_close(res[on][2], wr.grad, BF16_TOL, "dw", rell2)
+        assert wd.grad[:, :4].abs().max().item() == 0 and wd.grad[:, 4 + Cin:].abs().max().item() == 0
+    for a, bb, nm in zip(res[True], res[False], ("y", "dx", "dw")):
+        assert_close(a, bb, 2e-3, f"pixel-major vs patch kernel: {nm}", rell2)
+
+
 def test_conv2d_slab_views_and_prologue(gd):
     """conv reading a channel slice of a slab with the fused BN-affine+ReLU prologue, writing another slice"""
     ops, K = _ops()
