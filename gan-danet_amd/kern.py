@@ -664,6 +664,17 @@ def pack_bf16(s: Tensor, R: int, Cc: int, *, scale: Optional[Tensor] = None, sca
     return plain, tr
 
 
+def pack_nhwc16_affine(x: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
+    """(B, C, H, W) fp32 (per-image dense, possibly a channel slice of a slab) -> (B, H*W, C) bf16 pixel-major copy of
+    max(0, scale[c] x + shift[c]) (the BatchNorm + ReLU prologue of a dense layer); C % 8 == 0, H*W % 4 == 0"""
+    sbs = _bview(x, "pack input")
+    B, Cn, H, W = x.shape
+    out = torch.empty(B, H * W, Cn, device=x.device, dtype=torch.bfloat16)
+    L.check(lib().gd_pack_16_affine(_ptr(x), sbs, B, Cn, H * W, _ptr(scale), _ptr(shift), int(relu), None, 0, 0, _ptr(out),
+                                    H * W, Cn, 0, _stream()), "gd_pack_16_affine")
+    return out
+
+
 def augment_d4(x: Tensor, ops: Tensor, noise: Optional[Tensor] = None, noise_scale: float = 0.05) -> Tensor:
     """per-sample flip / flip / rot90 (+ noise) of a (B, C, H, W) batch; ``ops`` int32 (B,) op words (gandanet.h)"""
     _dense(x, "augment input")

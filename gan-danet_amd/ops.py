@@ -91,6 +91,7 @@ class Disc1TrunkFn(Function):
 # convolution (+ bias + activation)        nn.Conv2d  (generator.py / discriminator.py / VGG)
 # =====================================================================================================
 CONV_WIDE_NHWC = os.environ.get("GD_CONV_WIDE_NHWC", "1") != "0"
+DENSE_NHWC = os.environ.get("GD_DENSE_NHWC", "1") != "0"
 
 
 def _wide3x3(x, w, stride, pad, act, prec) -> bool:
@@ -253,22 +254,34 @@ class DenseBlockFn(Function):
         slab = torch.empty(B, C0 + nl * g, H, W, device=x.device, dtype=torch.float32)
         K.copy_slab(x, slab[:, :C0])
         saved: List[torch.Tensor] = []
+        # 16-bit mode: every layer's conv input max(0, bn(x)) is packed ONCE as a pixel-major bf16 copy; the forward conv
+        # (NHWC kernel, fp32 result straight into the slab), and in the backward the weight gradient, read that copy
+        # instead of gathering / normalising the fp32 NCHW slab in their staging loops
+        nhwc = (DENSE_NHWC and prec == L.PREC_BF16 and (H * W) % 8 == 0 and g % 8 == 0
+                and all((C0 + l * g) % 8 == 0 for l in range(nl)) and tuple(params[4].shape[2:]) == (3, 3))
+        packs: List[torch.Tensor] = []
         for l in range(nl):
             bw, bb, rm, rv, cw, cb = params[6 * l: 6 * l + 6]
             cl = C0 + l * g
             xin = slab[:, :cl]
             scale, shift, mean, invstd = _bn_prepare(xin, bw, bb, rm, rv, training, momentum, eps)
-            K.conv2d_fwd(xin, cw, cb, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True,
-                         out=slab[:, cl:cl + g])
+            if nhwc:
+                x16 = K.pack_nhwc16_affine(xin, scale, shift, True)
+                K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(_c(cw), 0), cb, g, H, W, out=slab[:, cl:cl + g])
+                packs.append(x16)
+            else:
+                K.conv2d_fwd(xin, cw, cb, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True,
+                             out=slab[:, cl:cl + g])
             saved += [scale, shift, mean, invstd, cw]
-        ctx.save_for_backward(slab, *saved)
-        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]])
+        ctx.save_for_backward(slab, *saved, *packs)
+        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]], nhwc)
         return slab
 
     @staticmethod
     def backward(ctx, dslab_in):
         slab, *saved = ctx.saved_tensors
-        nl, C0, g, training, prec, has_bias = ctx.cfg
+        nl, C0, g, training, prec, has_bias, nhwc = ctx.cfg
+        packs = saved[5 * nl:]
         B, _, H, W = slab.shape
         dslab = torch.empty(slab.shape, device=slab.device, dtype=torch.float32)  # accumulated into below
         K.copy_slab(_c(dslab_in), dslab)
@@ -278,10 +291,15 @@ class DenseBlockFn(Function):
             cl = C0 + l * g
             xin = slab[:, :cl]
             dy = dslab[:, cl:cl + g]
-            grads[6 * l + 4] = K.conv2d_wgrad(dy, xin, 3, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True)
+            if nhwc:
+                dy16, dyt16 = K.pack_bf16(_as3(dy), g, H * W, plain_shape=(g, H * W), t_shape=(H * W, g))
+                grads[6 * l + 4] = K.conv3x3_wgrad_packed(dy16, packs[l], H, W)
+                dxt = K.conv3x3_nhwc_f32out(dyt16, K.conv3x3_nhwc_pack(_c(cw), 1), None, cl, H, W)
+            else:
+                grads[6 * l + 4] = K.conv2d_wgrad(dy, xin, 3, 1, 1, prec, in_scale=scale, in_shift=shift, in_relu=True)
+                dxt = K.conv2d_dgrad(dy, cw, (H, W), 1, 1, prec)
             if has_bias[l]:
                 grads[6 * l + 5] = K.channel_sum(dy)
-            dxt = K.conv2d_dgrad(dy, cw, (H, W), 1, 1, prec)
             dgamma, dbeta, _ = K.bn_act_bwd(dxt, xin, scale, shift, mean, invstd, ACT_RELU, training,
                                             dx=dslab[:, :cl], accumulate_dx=True)
             grads[6 * l + 0], grads[6 * l + 1] = dgamma, dbeta

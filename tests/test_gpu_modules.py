@@ -209,6 +209,38 @@ def test_denseblock_vs_reference_fixture(gd, golden_dir):
     assert int(m.layers[0].bn.num_batches_tracked) == 1
 
 
+def test_denseblock_bf16_pixel_major_packs_vs_reference_fixture(gd, golden_dir):
+    """16-bit mode: every dense layer's conv input max(0, bn(x)) is packed once as a pixel-major bf16 copy
+    (gd_pack_16_affine) that feeds the NHWC forward kernel and the weight gradient; the data gradient runs on the packed dY.
+    Against the reference fixture at the 16-bit tolerances, and against the fp32-NCHW slab path (GD_DENSE_NHWC off), which
+    rounds the same operands at the same points."""
+    from gan_danet_amd.generator import DenseBlock
+    from gan_danet_amd import ops
+    fx = load_golden(golden_dir, "denseblock_64_8x8")
+    res = {}
+    for on in (True, False):
+        m = DenseBlock(4, 64, 24)
+        fill_module(m)
+        m.to(DEV).train()
+        x = fx["x"].to(DEV).requires_grad_(True)
+        old = ops.DENSE_NHWC
+        ops.DENSE_NHWC = on
+        try:
+            with gd.precision("bf16"):
+                y = m(x)
+                y.backward(fx["go"].to(DEV))
+        finally:
+            ops.DENSE_NHWC = old
+        assert_close(y, fx["y"], 2e-2, "y")
+        assert_close(x.grad, fx["gx"], 5e-2, "dx", rell2)
+        _check_param_grads(m, fx, 5e-2, rell2)
+        res[on] = (y.detach(), x.grad, {k: p.grad for k, p in m.named_parameters()})
+    assert_close(res[True][0], res[False][0], 2e-3, "pixel-major vs slab path: y", rell2)
+    assert_close(res[True][1], res[False][1], 5e-3, "pixel-major vs slab path: dx", rell2)
+    for k, gparam in res[True][2].items():
+        assert_close(gparam, res[False][2][k], 5e-3, f"pixel-major vs slab path: {k}", rell2)
+
+
 def test_discriminator1_vs_reference_fixture(gd, golden_dir):
     from gan_danet_amd import Discriminator1
     fx = load_golden(golden_dir, "disc1_64x64")
