@@ -92,13 +92,14 @@ class Disc1TrunkFn(Function):
 # =====================================================================================================
 CONV_WIDE_NHWC = os.environ.get("GD_CONV_WIDE_NHWC", "1") != "0"
 DENSE_NHWC = os.environ.get("GD_DENSE_NHWC", "1") != "0"
+WIDE_MIN_CIN = int(os.environ.get("GD_WIDE_MIN_CIN", "128"))     # 64 -> 64 at 512 x 512: conv time halves, the two packs eat it (measured equal)
 
 
 def _wide3x3(x, w, stride, pad, act, prec) -> bool:
     """wide 3x3 / stride 1 / pad 1 convs in 16-bit mode (the 2C -> C fuse conv of DANetAttention, generator.py:108, and the
     C -> 64 conv behind the last block): run on a pixel-major bf16 copy of the input through the NHWC kernel"""
     return (CONV_WIDE_NHWC and prec == L.PREC_BF16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and stride == 1
-            and pad == 1 and act in (ACT_NONE, ACT_RELU) and w.shape[1] >= 128 and w.shape[1] % 8 == 0 and w.shape[0] > 32
+            and pad == 1 and act in (ACT_NONE, ACT_RELU) and w.shape[1] >= WIDE_MIN_CIN and w.shape[1] % 8 == 0 and w.shape[0] > 32
             and w.shape[0] % 8 == 0 and (x.shape[2] * x.shape[3]) % 8 == 0)
 
 
