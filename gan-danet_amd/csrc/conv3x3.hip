@@ -748,7 +748,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
 // CS = true (Cout <= 32, the 24-channel dense layers): the waves are NW ci-CHUNKS sharing one 32-row dY tile -- the
 //   dY tile is staged once for 32 NW input channels, no wave multiplies an all-zero m-tile, and the workgroup has
 //   NW x 64 threads to keep loads in flight (with waves = m-tiles a Cout of 24 left 128 threads per workgroup).
-template <int NW, int S, bool CS>
+template <int NW, int S, bool CS, bool PIPED = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int BM = CS ? 32 : 32 * NW, NT = 64 * NW, NCH = CS ? NW : 1;
     constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
@@ -775,6 +775,74 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
     const bool vec_ok = (a.Wo % 4) == 0;
 
+    // Both operands 16-bit (dy16 channel-major, x16 pixel-major): the tile loop is software-pipelined -- the global loads
+    // of tile t + 1 are issued into registers before the MFMAs of tile t and stored to LDS after them, so the memory
+    // round trip no longer sits between two barriers with the matrix pipe idle
+    // (PIPED instantiations only: the host picks them when both 16-bit copies are given)
+    constexpr bool piped = PIPED;
+    constexpr int NDY = PIPED ? (BM * 32 + NT - 1) / NT : 1;     // 8-byte dY items per thread
+    constexpr int NXI = PIPED ? (4 * NCH * NPIXk + NT - 1) / NT : 1;   // 16-byte patch items per thread
+    uint2 rdy[NDY];
+    u32x4_t rxp[NXI];
+    auto load_regs = [&](int t) {
+        const int b = t / (a.tiles_y * a.tiles_x);
+        const int rem = t - b * (a.tiles_y * a.tiles_x);
+        const int ty_ = rem / a.tiles_x, tx_ = rem - ty_ * a.tiles_x;
+        const int y0 = ty_ * WTH, x0 = tx_ * TW;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int idx = tid + k * NT;
+            const int m = idx >> 5, v = idx & 31;
+            const int yy = y0 + (v >> 3), xx = x0 + (v & 7) * 4;
+            uint2 w = make_uint2(0u, 0u);
+            if (idx < BM * 32 && m0 + m < a.M && yy < a.Ho) {
+                const unsigned short* p = a.dy16 + ((long)b * a.M + m0 + m) * HWo + (long)yy * a.Wo + xx;
+                if (vec_ok && xx + 3 < a.Wo) {
+                    w = *reinterpret_cast<const uint2*>(p);
+                } else {
+                    unsigned int e0 = xx + 0 < a.Wo ? p[0] : 0u, e1 = xx + 1 < a.Wo ? p[1] : 0u;
+                    unsigned int e2 = xx + 2 < a.Wo ? p[2] : 0u, e3 = xx + 3 < a.Wo ? p[3] : 0u;
+                    w.x = e0 | (e1 << 16);
+                    w.y = e2 | (e3 << 16);
+                }
+            }
+            rdy[k] = w;
+        }
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int w = tid + k * NT;
+            const int oc = w / NPIXk;                   // (chunk, octet)
+            const int q = oc & 3, chk = oc >> 2;
+            const int pix = w - oc * NPIXk;
+            const int py = pix / PWk, px = pix - py * PWk;
+            const int iy = S * y0 - 1 + py, ix = S * x0 - 1 + px;
+            const int cb = c0 + chk * CK + q * 8;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (w < 4 * NCH * NPIXk && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cb < a.x16_ld)
+                v = *reinterpret_cast<const u32x4_t*>(a.x16 + (((long)b * a.H + iy) * a.W + ix) * a.x16_ld + cb);
+            rxp[k] = v;
+        }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < BM * 32) *reinterpret_cast<uint2*>(dys + (idx >> 5) * DYLD + (idx & 31) * 4) = rdy[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int w = tid + k * NT;
+            if (w < 4 * NCH * NPIXk) {
+                const int oc = w / NPIXk;
+                const int pix = w - oc * NPIXk;
+                *reinterpret_cast<u32x4_t*>(patch + ((oc >> 2) * NPIXk + pix) * LD + (oc & 3) * 8) = rxp[k];
+            }
+        }
+    };
+    if constexpr (piped) {
+        if (t_begin < t_end) load_regs(t_begin);
+    }
+
     for (int t = t_begin; t < t_end; ++t) {
         const int b = t / (a.tiles_y * a.tiles_x);
         const int rem = t - b * (a.tiles_y * a.tiles_x);
@@ -783,6 +851,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
         const float* dyb = a.dy + (long)b * a.dy_bs;
         const float* xb = a.x + (long)b * a.x_bs;
 
+        if constexpr (piped) {
+            store_regs();
+        } else {
         // ---- dY tile -> [co][pixel] bf16 : 4-pixel vectors, BM*32 of them ----
 #pragma unroll 4
         for (int k = 0; k < 16 / (CS ? NW : 1) + (CS && (16 % NW) ? 1 : 0); ++k) {
@@ -873,7 +944,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
                 dst[j] = gd_pack_bf2(v0, v1);
             }
         }
+        }
         __syncthreads();
+        if constexpr (piped) {
+            if (t + 1 < t_end) load_regs(t + 1);
+        }
 
         // ---- 8 k-steps of 16 pixels x 9 taps ----
 #pragma unroll 2
@@ -960,6 +1035,11 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16
     if (cs) {
         if (cs_nw == 3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<3, 1, true>), grid, dim3(192), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, true>), grid, dim3(256), 0, s, a);
+    } else if (stride == 1 && a.dy16 && a.x16 && best_nw >= 4) {
+        // both operands 16-bit: software-pipelined staging (368->184: 8.4 -> 6.4 ms; the 2-wave block spills under it
+        // and stays on the plain loop: 1.85 vs 2.20 ms at 184->64)
+        if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 1, false, true>), grid, dim3(384), 0, s, a);
     } else if (stride == 1) {
         if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1, false>), grid, dim3(128), 0, s, a);
         else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, false>), grid, dim3(256), 0, s, a);
