@@ -40,6 +40,37 @@ __global__ __launch_bounds__(256) void disc_stem_fwd_kernel(const float* __restr
     __syncthreads();
     const int oct = Co / 8;
     const long HW = (long)H * W, HWo = (long)Ho * Wo;
+    if (Ci == 1 && Co == 64) {
+        // single-channel image, 64 filters: the thread's octet is fixed over the grid stride, weights and biases in registers
+        const int o8 = (threadIdx.x & 7) * 8;
+        float wr[9][8], br[8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wr[t][k] = wl[t * 64 + o8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) br[k] = bias ? bias[o8 + k] : 0.f;
+        for (long p = ((long)blockIdx.x * 256 + threadIdx.x) >> 3; p < npix_total; p += ((long)gridDim.x * 256) >> 3) {
+            const long b = p / HWo;
+            const int rem = (int)(p - b * HWo);
+            const int py = rem / Wo, px = rem - py * Wo;
+            const float* plane = img + b * HW;
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = br[k];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = 2 * py + t / 3 - 1, ix = 2 * px + t % 3 - 1;
+                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? plane[(long)iy * W + ix] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(v, wr[t][k], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * slope;
+            *reinterpret_cast<u32x4_t*>(y + p * 64 + o8) = pack8(acc);
+        }
+        return;
+    }
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < npix_total * oct; idx += (long)gridDim.x * 256) {
         const long p = idx / oct;
         const int o8 = (int)(idx - p * oct) * 8;
