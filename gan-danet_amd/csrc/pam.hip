@@ -765,8 +765,8 @@ extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int 
 extern "C" size_t gd_pam_bwd64_scratch_bytes(int Npad, int deterministic);
 extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                   const float* lse, const float* delta, int nb, int N, int Npad, int Cp, int f16,
-                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, void* scratch,
-                                  void* stream);
+                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, long out_bs,
+                                  void* scratch, void* stream);
 
 // Backward forms (gandanet.h GD_PAM_BWD_*):
 //   0 K64_ATOMIC : 4 waves x 64 keys, one wave per SIMD, fp32 atomics for dQ            (default, fastest)
@@ -788,8 +788,10 @@ static int pam_k64_vreg() {
 
 extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                 const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
-                                float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream) {
+                                float* dqn, float* dkn, float* dv, long out_bs, void* scratch, size_t scratch_bytes,
+                                void* stream) {
     GD_CHECK_ARG(qt && kt && kn && vt && dot_ && lse && delta && dqn && dkn && dv, "gd_pam_flash_bwd: null pointer");
+    GD_CHECK_ARG(out_bs == 0 || (form == 0 && out_bs >= (long)Cp * Npad), "gd_pam_flash_bwd: a shared output batch stride needs form 0");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_bwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(Cp > 0 && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_bwd: Cp must be a multiple of 32 <= 192");
     GD_CHECK_ARG(form >= 0 && form <= 3, "gd_pam_flash_bwd: form must be 0..3");
@@ -806,9 +808,10 @@ extern "C" int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, 
             const int nb = B - b0 < slice ? B - b0 : slice;
             const long o32 = (long)b0 * Npad * 32, oc = (long)b0 * Npad * Cp, on = (long)b0 * N;
             if (form <= 1) {
+                const long oq = out_bs ? (long)b0 * out_bs : o32, ov = out_bs ? (long)b0 * out_bs : oc;
                 const int rcode = gd_pam_bwd64_slice(q + o32, k + o32, kT + o32, v + oc, dO + oc, lse + on, delta + on, nb, N,
-                                                     Npad, Cp, f16, pam_k64_vreg(), form == 1, dqn + o32, dkn + o32, dv + oc,
-                                                     scratch, stream);
+                                                     Npad, Cp, f16, pam_k64_vreg(), form == 1, dqn + oq, dkn + oq, dv + ov,
+                                                     out_bs, scratch, stream);
                 if (rcode) return rcode;
             } else {
                 PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_bwd_dkv3_kernel<CT, true, 8>), dim3(Npad / 256, nb), dim3(512), 0, s,

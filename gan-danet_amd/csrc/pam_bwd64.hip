@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pam_rowconst_kernel(const float* __restri
 
 // dq_acc (B, Npad, 32) fp32 [query][d]  ->  dqn (B, 32, Npad) [d][query]
 __global__ __launch_bounds__(256) void pam_dq_transpose_kernel(const float* __restrict__ acc, int Npad,
-                                                              float* __restrict__ dqn) {
+                                                              float* __restrict__ dqn, long dqn_bs) {
     __shared__ float tile[64][33];
     const int b = blockIdx.y, i0 = blockIdx.x * 64;
     for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void pam_dq_transpose_kernel(const float* __re
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
         const int d = idx >> 6, q = idx & 63;
-        dqn[((long)b * 32 + d) * Npad + i0 + q] = tile[q][d];
+        dqn[(long)b * dqn_bs + (long)d * Npad + i0 + q] = tile[q][d];
     }
 }
 
@@ -190,7 +190,7 @@ template <int CT, bool F16, int VREG, bool ATOMIC, int ORDER = 0>
 __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ rc,
-    int Npad, float* __restrict__ dkn, float* __restrict__ dv, void* __restrict__ dq_out) {
+    int Npad, float* __restrict__ dkn, float* __restrict__ dv, void* __restrict__ dq_out, long dk_bs, long dv_bs) {
     constexpr int CP = CT * 32;
     constexpr int DOLD = CP + 32;                  // dO rows, chunk-swizzled (do_off)
     constexpr int DROWCH = DOLD / 8;               // 16-byte chunks per dO row
@@ -708,9 +708,9 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dv[((long)b * CP + ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[k2][ct][e];
+            for (int e = 0; e < 16; ++e) dv[(long)b * dv_bs + (long)(ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[k2][ct][e];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dkn[((long)b * 32 + acc_row(e, h)) * Npad + j] = dkacc[k2][e] * LN2;   // Q^T was q * log2 e
+        for (int e = 0; e < 16; ++e) dkn[(long)b * dk_bs + (long)acc_row(e, h) * Npad + j] = dkacc[k2][e] * LN2;   // Q^T was q * log2 e
     }
 }
 
@@ -730,8 +730,8 @@ namespace {
 template <int CT, bool F16, int VREG, bool ATOMIC>
 void launch_k64(dim3 grid, hipStream_t s, const unsigned short* q, const unsigned short* k, const unsigned short* kT,
                 const unsigned short* v, const unsigned short* dO, const float* rc, int Npad, float* dkn, float* dv,
-                void* dq_out) {
-    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC, 8>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out);
+                void* dq_out, long dk_bs, long dv_bs) {
+    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC, 8>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out, dk_bs, dv_bs);
 }
 }  // namespace
 
@@ -748,8 +748,11 @@ extern "C" void gd_pam_k64_variant(int order, int vreg) {
 // one batch slice through the 64-keys-per-wave backward; scratch holds `images` images' worth
 extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                                   const float* lse, const float* delta, int nb, int N, int Npad, int Cp, int f16,
-                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, void* scratch,
-                                  void* stream) {
+                                  int vreg, int deterministic, float* dqn, float* dkn, float* dv, long out_bs,
+                                  void* scratch, void* stream) {
+    // out_bs: batch stride (elements) shared by dqn / dkn / dv when they are row blocks of ONE (B, rows, Npad) buffer;
+    // 0 = three dense tensors
+    const long dq_bs = out_bs ? out_bs : 32L * Npad, dk_bs = out_bs ? out_bs : 32L * Npad, dv_bs = out_bs ? out_bs : (long)Cp * Npad;
     hipStream_t s = (hipStream_t)stream;
     if (g_k64_vreg) vreg = g_k64_vreg;
     float* rc = reinterpret_cast<float*>(scratch);
@@ -764,7 +767,7 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
     const dim3 grid(Npad / 256, nb);
     const unsigned short *q = (const unsigned short*)qt, *k = (const unsigned short*)kt, *kT = (const unsigned short*)kn;
     const unsigned short *v = (const unsigned short*)vt, *dO = (const unsigned short*)dot_;
-#define K64_ARGS grid, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr
+#define K64_ARGS grid, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs
 #define K64_CASE(CT_)                                                                                   \
     case CT_:                                                                                           \
         if (f16) {                                                                                      \
@@ -781,15 +784,15 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
     if (g_k64_order && Cp == 192 && !f16 && !deterministic) {     // schedule A/B variants (bench tooling only)
 #define K64_ORD(O_)                                                                                          \
     case O_:                                                                                                 \
-        if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
-        else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr); \
+        if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs); \
+        else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs); \
         break;
         switch (g_k64_order == 1 ? 0 : -1) {      // variant 1 = the compiler-scheduled AGPR-form loop (ORDER 0)
             K64_ORD(0)
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD
-        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn);
+        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn, dq_bs);
         GD_LAUNCH_CHECK();
         return 0;
     }
@@ -799,10 +802,12 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
     }
 #undef K64_CASE
 #undef K64_ARGS
-    if (deterministic)
+    if (deterministic) {
+        if (out_bs) { gd_set_error("gd_pam_flash_bwd: the deterministic dQ reduction writes a dense dqn (out_bs must be 0)"); return -1; }
         gd_pam_dq_reduce_launch(dq_scr, Npad / 256, Npad, nb, dqn, stream);
+    }
     else
-        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn);
+        hipLaunchKernelGGL(pam_dq_transpose_kernel, dim3(Npad / 64, nb), dim3(256), 0, s, (const float*)dq_scr, Npad, dqn, dq_bs);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -777,7 +777,8 @@ def pam_bwd_form() -> int:
 
 
 def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv, r_alg: int = 32, c_alg: int = 0,
-                  f16: bool = False, form: Optional[int] = None):
+                  f16: bool = False, form: Optional[int] = None, out_bs: int = 0):
+    """out_bs != 0 (form 0 only): dqn / dkn / dv are row blocks of one (B, rows, Npad) buffer with that batch stride"""
     form = pam_bwd_form() if form is None else form
     scratch, scratch_bytes = None, 0
     per_image = int(lib().gd_pam_bwd_scratch_bytes(Npad, form))
@@ -789,8 +790,8 @@ def pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Npad, Cp, dqn, dkn, dv
     # algorithmic work of the backward = 2x forward: 4 N^2 (r + C) per image
     with _Bracket("pam_flash_bwd", 4.0 * N * N * (r_alg + (c_alg or Cp)) * B):
         L.check(lib().gd_pam_flash_bwd(_ptr(qt), _ptr(kt), _ptr(kn), _ptr(vt), _ptr(dot_), _ptr(lse), _ptr(delta), B,
-                                       N, Npad, Cp, int(f16), int(form), _ptr(dqn), _ptr(dkn), _ptr(dv), _ptr(scratch),
-                                       scratch_bytes, _stream()), "gd_pam_flash_bwd")
+                                       N, Npad, Cp, int(f16), int(form), _ptr(dqn), _ptr(dkn), _ptr(dv), int(out_bs),
+                                       _ptr(scratch), scratch_bytes, _stream()), "gd_pam_flash_bwd")
 
 
 # =====================================================================================================

@@ -92,6 +92,7 @@ class Disc1TrunkFn(Function):
 # =====================================================================================================
 CONV_WIDE_NHWC = os.environ.get("GD_CONV_WIDE_NHWC", "1") != "0"
 DENSE_NHWC = os.environ.get("GD_DENSE_NHWC", "1") != "0"
+PAM_CAT = os.environ.get("GD_PAM_CAT", "1") != "0"        # q / k / v projections (and their gradients) as one GEMM each
 WIDE_MIN_CIN = int(os.environ.get("GD_WIDE_MIN_CIN", "128"))     # 64 -> 64 at 512 x 512: conv time halves, the two packs eat it (measured equal)
 
 
@@ -328,9 +329,22 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
     r = wq.shape[0]
     x3 = x.view(B, Cn, N)
     fused = prec == L.PREC_BF16 and Cn <= 192 and r <= 31
-    q = K.conv2d_fwd(x, wq, bq, 1, 0, prec).view(B, r, N)
-    k = K.conv2d_fwd(x, wk, bk, 1, 0, prec).view(B, r, N)
-    v = K.conv2d_fwd(x, wv, bv, 1, 0, prec).view(B, Cn, N)
+    if fused and PAM_CAT and (bq is None) == (bk is None) == (bv is None):
+        # q, k, v as ONE 1x1 conv over the concatenated weights: x is read once instead of three times
+        wc = torch.empty(2 * r + Cn, Cn, 1, 1, device=x.device, dtype=torch.float32)
+        for w_, lo in ((wq, 0), (wk, r), (wv, 2 * r)):
+            K.copy_slab(_c(w_).view(1, w_.shape[0], Cn), wc.view(1, 2 * r + Cn, Cn)[:, lo:lo + w_.shape[0]])
+        bc = None
+        if bq is not None:
+            bc = torch.empty(2 * r + Cn, device=x.device, dtype=torch.float32)
+            for b_, lo in ((bq, 0), (bk, r), (bv, 2 * r)):
+                K.copy_slab(b_.view(1, -1, 1), bc.view(1, -1, 1)[:, lo:lo + b_.numel()])
+        y3 = K.conv2d_fwd(x, wc, bc, 1, 0, prec).view(B, 2 * r + Cn, N)
+        q, k, v = y3[:, :r], y3[:, r:2 * r], y3[:, 2 * r:]
+    else:
+        q = K.conv2d_fwd(x, wq, bq, 1, 0, prec).view(B, r, N)
+        k = K.conv2d_fwd(x, wk, bk, 1, 0, prec).view(B, r, N)
+        v = K.conv2d_fwd(x, wv, bv, 1, 0, prec).view(B, Cn, N)
     if fused:
         Np, Cp = _npad(N), _cp(Cn)
         # q goes in pre-scaled by log2 e; a spare padded channel of V carries ones (softmax denominator by MFMA)
@@ -340,6 +354,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
         kn, kt = K.pack_bf16(k, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=f16)
         vn, vt = K.pack_bf16(v, Cn, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones, f16=f16)
         del q, k, v
+        y3 = None
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
         k_sqmax = K.pam_key_sqnorm_max(kt, N, f16) if K.PAM_NOMAX else None
@@ -372,6 +387,25 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         dgamma_p = K.dot(d_raw, None)
         f16 = qt.dtype == torch.float16          # the operand type the forward packed
         _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, t_shape=(Np, Cp), f16=f16)
+        if PAM_CAT and Np == N and K.pam_bwd_form() == L.PAM_BWD_K64_ATOMIC:
+            # dq | dk | dv as row blocks of ONE buffer: the three projection data / weight / bias gradients below become
+            # one GEMM each over it (dx read-modify-written once instead of three times, x read once)
+            R = 64 + Cp
+            dcat = torch.empty(B, R, Np, device=x.device, dtype=torch.float32)
+            K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dcat[:, 0:32], dcat[:, 32:64], dcat[:, 64:],
+                            r_alg=r, c_alg=Cn, f16=f16, out_bs=R * Np)
+            wcat = torch.zeros(R, Cn, 1, 1, device=x.device, dtype=torch.float32)     # rows beyond r / C stay zero
+            for w_, lo in ((wq, 0), (wk, 32), (wv, 64)):
+                K.copy_slab(_c(w_).view(1, w_.shape[0], Cn), wcat.view(1, R, Cn)[:, lo:lo + w_.shape[0]])
+            dcat4 = dcat.view(B, R, H, W)
+            dwc = K.conv2d_wgrad(dcat4, x, 1, 1, 0, prec)
+            dbc = K.channel_sum(dcat4) if any(has_bias) else None
+            K.conv2d_dgrad(dcat4, wcat, (H, W), 1, 0, prec, out=dx.view(B, Cn, H, W), accumulate=True)
+            grads = []
+            for (lo, n), hb in zip(((0, r), (32, r), (64, Cn)), has_bias):
+                grads.append(dwc[lo:lo + n])
+                grads.append(dbc[lo:lo + n] if hb else None)
+            return (*grads, dgamma_p)
         dqn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)

@@ -341,6 +341,8 @@ int gd_pam_key_sqnorm_max(const void* kt, int B, int N, int Npad, int f16, float
  *   1 K64_PARTS   the same kernel storing dQ as one bf16 part per 256-key block + a streaming sum (reproducible)
  *   2 K32_PARTS   8 waves x 32 keys per workgroup, bf16 dQ parts (the round-1 kernel; reproducible; bf16 only)
  *   3 TWO_KERNEL  dK/dV kernel, then a query-parallel kernel that recomputes S and dP for dQ (no scratch; bf16 only)
+ * out_bs: 0, or (form 0 only) the batch stride in elements shared by dqn, dkn, dv when the caller passes them as row
+ *   blocks of ONE (B, rows, Npad) buffer -- the three projection gradients can then run as one GEMM over that buffer.
  * scratch: caller-owned, >= gd_pam_bwd_scratch_bytes(Npad, form) (= one image's worth; more lets more images go per
  * launch); may be NULL for form 3. */
 #define GD_PAM_BWD_K64_ATOMIC 0
@@ -353,7 +355,7 @@ size_t gd_pam_bwd_scratch_bytes(int Npad, int form);
 void gd_pam_k64_variant(int order, int vreg);
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
                      const float* lse, const float* delta, int B, int N, int Npad, int Cp, int f16, int form,
-                     float* dqn, float* dkn, float* dv, void* scratch, size_t scratch_bytes, void* stream);
+                     float* dqn, float* dkn, float* dv, long out_bs, void* scratch, size_t scratch_bytes, void* stream);
 
 /* test.ipynb c1:69-85 mild_histogram_matching, per sample of a batch: out[b] = (1 - weight) * src[b] + weight *
  * interp(cdf_src(src[b]), cdf_ref, sorted unique ref[b]) with numpy's np.unique / np.interp semantics (float64 result, as
