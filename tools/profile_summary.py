@@ -44,6 +44,9 @@ def stats(d, top):
     print(f"{'TOTAL':70s} {sum(v[0] for v in rows.values()):6d} {tot:10.3f}")
 
 
+PREFIX = "pam_"          # kernels summarised by the pmc mode (third argument overrides)
+
+
 def pmc(d):
     # counter_collection.csv: one row per dispatch and counter
     vals = defaultdict(lambda: defaultdict(list))
@@ -55,7 +58,7 @@ def pmc(d):
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     for k in sorted(vals, key=lambda k: -sum(dur.get(k, [0]))):
-        if not k.startswith("pam_"):
+        if not k.startswith(PREFIX):
             continue
         c = {n: sum(v) / len(v) for n, v in vals[k].items()}
         ms = sum(dur[k]) / max(1, len(dur[k]))
@@ -87,4 +90,6 @@ if __name__ == "__main__":
     if mode == "stats":
         stats(d, int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[3] == "--top" else 40)
     else:
+        if len(sys.argv) > 3:
+            PREFIX = sys.argv[3]
         pmc(d)
