@@ -326,6 +326,40 @@ def test_transpose_and_pack(gd):
     assert torch.equal(tr.float().cpu(), ref.transpose(1, 2).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("R,Cc,Rp,ldp,ldt", [(23, 200, 32, 256, 32), (184, 456, 192, 512, 192), (70, 64, 72, 64, 72)])
+def test_pack16_tile64_kernel_aligned_shapes(gd, R, Cc, Rp, ldp, ldt, f16):
+    """the 64 x 64-tile pack (16-byte accesses; taken when Cc % 4 == 0 and the leading dimensions % 8 == 0) against the
+    definition: zero padding, scale, the row of ones, the perm16 key order of the plain copy, both 16-bit types, the
+    source as a channel slice of a wider tensor; and gd_pack_16_affine (per-row affine + ReLU first)"""
+    from gan_danet_amd import kern as K
+    B = 2
+    wide = seeded((B, R + 5, Cc), 61)
+    src = wide[:, 3:3 + R]
+    dt = torch.float16 if f16 else torch.bfloat16
+    ones = Rp - 1 if R < Rp else -1
+    plain, tr = K.pack_bf16(wide.to(DEV)[:, 3:3 + R], R, Cc, scale_imm=1.5, plain_shape=(Rp, ldp), t_shape=(ldp, ldt),
+                            perm16=True, ones_row=ones, f16=f16)
+    ref = torch.zeros(B, Rp, ldp)
+    ref[:, :R, :Cc] = 1.5 * src
+    if ones >= 0:
+        ref[:, ones, :] = 1.0
+    reft = torch.zeros(B, ldp, ldt)
+    reft[:, :, :Rp] = ref.transpose(1, 2)[:, :, :min(Rp, ldt)] if Rp <= ldt else ref.transpose(1, 2)[:, :, :ldt]
+    c = torch.arange(ldp)
+    perm = (c & ~15) | ((c & 3) | ((c & 4) << 1) | ((c & 8) >> 1))     # plain[.., perm(c)] = value of column c
+    refp = torch.zeros_like(ref)
+    refp[:, :, perm] = ref
+    assert torch.equal(plain.float().cpu(), refp.to(dt).float())
+    assert torch.equal(tr.float().cpu(), reft.to(dt).float())
+    if not f16 and R % 8 == 0:
+        sc, sh = seeded((R,), 62, 0.5), seeded((R,), 63, 0.3)
+        xin = wide.to(DEV).view(B, R + 5, Cc // 4, 4)[:, 3:3 + R]          # (B, R, H, W) channel slice
+        out = K.pack_nhwc16_affine(xin, sc.to(DEV), sh.to(DEV), True)
+        refa = torch.relu(src * sc[None, :, None] + sh[None, :, None]).transpose(1, 2)
+        assert_close(out.float(), refa, 8e-3, "affine + ReLU pack (the kernel fuses the multiply-add: one bf16 ulp)")
+
+
 @pytest.mark.parametrize("shape", [(2, 72, 24, 64, 184), (1, 368, 16, 32, 184), (1, 64, 40, 96, 64), (2, 3, 33, 70, 64),
                                    # Cout <= 32 (dense layers): weight gradient with waves = ci chunks (2, 4, 3+2, 3)
                                    (2, 64, 16, 32, 24), (1, 112, 9, 40, 24), (1, 160, 8, 32, 24), (1, 88, 8, 64, 32)])
