@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (config 3: 32, config 2: 32, config 5: 1)")
     ap.add_argument("--tile", type=int, default=None, help="generator input tile (config 3: 256, 2: 128, 5: 512)")
     ap.add_argument("--channels", type=int, default=8)
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32", "mixed"])
     ap.add_argument("--no-perceptual", action="store_true", help="exploration only; the reported config has it on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
@@ -111,14 +111,54 @@ def g_out_rel_err(gd, dev, precision):
             "north_star": "1e-3 (held by --precision fp32: 4e-6; 16-bit operand modes: see profiles/r02_parity_report.json)"}
 
 
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` with no launcher on the command line: start N fresh worker processes of this script
+    (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.  This parent
+    never touches the GPU (no HIP call before or after the spawn, no exec): rank 0 writes the JSON line to our stdout,
+    the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:            # one rank failed: the others would hang in their next collective
+                        q.terminate()
+            time.sleep(0.2)
+    except BaseException:
+        for q in procs:
+            q.kill()
+        raise
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     cfg = args.config
     defaults = {2: (32, 128, "bf16"), 3: (32, 256, "bf16"), 4: (32, 256, "bf16"), 5: (1, 512, "fp16")}[cfg]
     args.batch = defaults[0] if args.batch is None else args.batch
     args.tile = defaults[1] if args.tile is None else args.tile
     args.precision = defaults[2] if args.precision is None else args.precision
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_gpu_rehearsal = args.backend != "nccl"
@@ -287,6 +327,10 @@ def main():
             "value": round(args.steps * B * world / dt, 3),
             "unit": "samples/s",
             "n_gpus": world,
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
+                      "backend": (dist.get_backend() if world > 1 else None),
+                      "devices": ("one rank per GPU (LOCAL_RANK)" if not one_gpu_rehearsal or world == 1
+                                  else "REHEARSAL: all ranks on cuda:0")},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),

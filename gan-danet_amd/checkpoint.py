@@ -56,8 +56,25 @@ class EarlyStopping:
         self.best_loss = float("inf")
         self.trigger_times = 0
 
+    def _rank_uniform(self, loss: float, G: nn.Module) -> float:
+        """Under data parallelism every rank holds its own SHARD's mean loss: comparing those would let best_loss /
+        trigger_times drift apart, one rank reach its patience and enter ``finish``'s barrier while the others start the
+        next step's collectives.  The decision is made on the mean over ranks (one scalar all-reduce per epoch), so all
+        ranks save / count / stop together.  Independent members (``all_ranks``) keep their own loss."""
+        import torch.distributed as dist
+        if self.all_ranks or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return float(loss)
+        dev = next(G.parameters()).device
+        if dist.get_backend() == "gloo":
+            dev = torch.device("cpu")
+        t = torch.tensor([float(loss)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.item() / dist.get_world_size()
+
     def step(self, avg_epoch_loss_g: float, G: nn.Module) -> bool:
-        """returns True when training should stop (the best weights are then already loaded back into G)"""
+        """returns True when training should stop (the best weights are then already loaded back into G); collective
+        under data parallelism (call on every rank, once per epoch)"""
+        avg_epoch_loss_g = self._rank_uniform(avg_epoch_loss_g, G)
         if avg_epoch_loss_g < self.best_loss - self.min_delta:
             self.best_loss = avg_epoch_loss_g
             self.trigger_times = 0

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
             }
         q2 += __shfl_xor(q2, 32, 64);
         const float bound = sqrtf(q2 * k_sqmax[b]) * 1.0001f;
-        nomax = __all(bound <= (F16 ? 13.f : 60.f));
+        // WORKGROUP-uniform choice: the two sweep instantiations each own a barrier site in the key-tile loop (the LDS-DMA
+        // ring relies on them), so all eight waves must enter the same one
+        nomax = __syncthreads_and(bound <= (F16 ? 13.f : 60.f)) != 0;
     }
     if (nomax) sweep(std::true_type{});
     else sweep(std::false_type{});

@@ -22,6 +22,8 @@ class Discriminator1(nn.Module):
         self.fc1 = LazyLinear(1024)
         self.fc2 = Linear(1024, 1)
         self.activation = LeakyReLU(negative_slope=0.2, inplace=True)
+        for m in (self.conv1, self.conv2, self.conv3, self.conv4):
+            m.layer_class = "disc"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         convs = (self.conv1, self.conv2, self.conv3, self.conv4)

@@ -25,8 +25,9 @@ from .layers import ACT_RELU, BatchNorm2d, Conv2d, ReLU, Sigmoid, UpsampleBicubi
 class _ConvBnRelu(nn.Sequential):
     """[Conv2d, BatchNorm2d, ReLU] with the reference's indices; BN+ReLU run as one kernel."""
 
-    def __init__(self, cin: int, cout: int, k: int, pad: int) -> None:
+    def __init__(self, cin: int, cout: int, k: int, pad: int, layer_class: str = "other") -> None:
         super().__init__(Conv2d(cin, cout, kernel_size=k, padding=pad, bias=False), BatchNorm2d(cout), ReLU())
+        self[0].layer_class = layer_class
 
     def forward(self, x):
         return self[1](self[0](x), ACT_RELU)
@@ -105,7 +106,7 @@ class DANetAttention(nn.Module):
         super().__init__()
         self.position_attention = PAMModule(channels)
         self.channel_attention = CAMModule(channels)
-        self.fuse = _ConvBnRelu(2 * channels, channels, 3, 1)
+        self.fuse = _ConvBnRelu(2 * channels, channels, 3, 1, "fuse3x3")
 
     def forward(self, x):
         pa = self.position_attention
@@ -133,7 +134,7 @@ class FlexibleUpsamplingModule(nn.Module):
     def __init__(self, input_channels: int = 40, growth_rate: int = 24, num_blocks: int = 3,
                  num_layers_per_block: int = 4, attention_type: Optional[str] = "danet") -> None:
         super().__init__()
-        self.initial = _ConvBnRelu(input_channels, 64, 3, 1)
+        self.initial = _ConvBnRelu(input_channels, 64, 3, 1, "stem")
         self.dense_blocks = nn.ModuleList()
         self.transition_layers = nn.ModuleList()
         self.attention_modules = nn.ModuleList()
@@ -153,6 +154,10 @@ class FlexibleUpsamplingModule(nn.Module):
             Conv2d(width, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), ReLU(), UpsampleBicubic2x(),
             Conv2d(64, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), ReLU(), UpsampleBicubic2x())
         self.final = Conv2d(64, 1, kernel_size=3, padding=1)
+        for m in (self.upsample[0], self.upsample[4], self.final):
+            m.layer_class = "decoder"
+        for m in self.channel_adjust:
+            m.layer_class = "conv1x1"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.initial(x)
@@ -180,7 +185,7 @@ class FlexibleUpsamplingModule(nn.Module):
         # (7x less HBM traffic there, no 64-channel 4H x 4W tensor kept for backward).  Same parameters, same
         # result up to fp32 re-association.
         w9 = fw.reshape(fw.shape[1], 9).t()                # (9, 64): w9[tap][ch]
-        t = ops.conv2d(c, w9.reshape(9, -1, 1, 1).contiguous())        # .t()/.reshape(): views + one layout copy
+        t = ops.conv2d(c, w9.reshape(9, -1, 1, 1).contiguous(), layer="conv1x1")   # .t()/.reshape(): views + one layout copy
         u = up[7](t)                                       # (B, 9, 4H, 4W)
         # composed operators (9 x C_k) = w9 (9 x 64) . A_k (64 x C_k): a 1x1 conv over A_k read as a 64-channel,
         # C_k-pixel image (exact-fp32 MFMA kernel whatever the configured precision: these are weights)

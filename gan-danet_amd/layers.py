@@ -16,6 +16,8 @@ class Conv2d(nn.Conv2d):
     models/ package is of this form (generator.py:20,34,63,108-110,148,188,214,218,222,228; discriminator.py:14-51,
     62-65); other geometries are refused loudly rather than mis-computed."""
 
+    layer_class = "other"        # config.LAYER_CLASSES entry whose operand type this conv follows (set by the owner)
+
     def _geometry(self):
         k, s, p = self.kernel_size, self.stride, self.padding
         if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or self.groups != 1 or self.dilation != (1, 1) \
@@ -25,7 +27,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x: torch.Tensor, act: int = ACT_NONE) -> torch.Tensor:
         s, p = self._geometry()
-        return ops.conv2d(x, self.weight, self.bias, s, p, act)
+        return ops.conv2d(x, self.weight, self.bias, s, p, act, None, self.layer_class)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -52,6 +52,7 @@ class PerceptualLoss(nn.Module):
             if ent[0] == "c":
                 cout = int(ent[1:])
                 mods.append(Conv2d(cin, cout, kernel_size=3, padding=1))
+                mods[-1].layer_class = "vgg"
                 cin = cout
             elif ent == "r":
                 mods.append(ReLU())
@@ -146,8 +147,8 @@ class PerceptualLoss(nn.Module):
         return plan
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        from .config import config
-        if (config.precision != "fp32" and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
+        from .config import sixteen_bit
+        if (sixteen_bit("vgg") and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
                 and x.shape[3] % 8 == 0 and self._nhwc_plan() is not None):
             return _PerceptualNhwcFn.apply(x, y, self)
         x3 = x if x.shape[1] == 3 else ops.repeat_channels(x, 3)
@@ -264,10 +265,10 @@ class BCEWithLogitsLoss(nn.Module):
 
     def forward(self, logits: torch.Tensor, target) -> torch.Tensor:
         if torch.is_tensor(target):
-            if target.numel() == 1:
-                target = float(target)
+            if target.dim() == 0 and not target.is_cuda and not target.requires_grad:
+                target = float(target)         # a 0-dim host constant: no device sync, no gradient to keep
             else:
-                if target.shape != logits.shape:
+                if target.shape != logits.shape:   # as torch.nn.BCEWithLogitsLoss: no silent broadcast
                     raise ValueError(f"target {tuple(target.shape)} must match the logits {tuple(logits.shape)}")
                 return ops.bce_with_logits_target(logits, target)
         return ops.bce_with_logits(logits, float(target))

@@ -17,18 +17,20 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import kern as K
-from .config import config
+from .config import config, sixteen_bit
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY02, L.ACT_SIGMOID
 
 
-def _prec() -> int:
-    return L.PREC_FP32 if config.precision == "fp32" else L.PREC_BF16
+def _prec(layer: str = "other") -> int:
+    """MFMA operand type of a layer class under the configured mode (config.sixteen_bit): 16-bit or exact f32"""
+    return L.PREC_BF16 if sixteen_bit(layer) else L.PREC_FP32
 
 
 def _pam_f16() -> bool:
-    """fp16 operand mode of the fused PAM kernels (config.precision == "fp16"); all other kernels stay bf16"""
-    return config.precision == "fp16"
+    """IEEE fp16 operands in the fused PAM kernels ("fp16": BASELINE config 5; "mixed": 3 more mantissa bits than bf16 at
+    the same MFMA rate); all other kernels never take fp16"""
+    return config.precision in ("fp16", "mixed")
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -44,7 +46,7 @@ DISC_NHWC = os.environ.get("GD_DISC_NHWC", "1") != "0"
 def disc1_trunk_eligible(x: torch.Tensor, ws) -> bool:
     """16-bit operand mode, non-deterministic mode (the bias sums and weight gradients use atomics), the reference's
     channel ladder (.. -> 64 -> .. multiples of 8), at most 4 image channels"""
-    return (DISC_NHWC and config.precision != "fp32" and not K.DETERMINISTIC and x.dim() == 4 and x.shape[1] <= 4
+    return (DISC_NHWC and sixteen_bit("disc") and not K.DETERMINISTIC and x.dim() == 4 and x.shape[1] <= 4
             and ws[0].shape[0] == 64 and all(w.shape[0] % 8 == 0 and w.shape[2:] == (3, 3) for w in ws))
 
 
@@ -63,13 +65,14 @@ class Disc1TrunkFn(Function):
         acts = [K.disc_stem_fwd(x, _c(w1), b1, Disc1TrunkFn.SLOPE)]
         for w, b in zip(ws[1:], bs[1:]):
             acts.append(K.conv3x3_nhwc_s2(acts[-1], K.conv3x3_nhwc_pack(_c(w), 0), b, w.shape[0], 2, Disc1TrunkFn.SLOPE))
-        ctx.x, ctx.acts, ctx.ws = x, acts, ws
+        ctx.save_for_backward(x, *ws, *acts)       # autograd's version check guards x / the weights against in-place edits
         ctx.has_bias = tuple(b is not None for b in bs)
         return K.nhwc_flatten_fwd(acts[-1])
 
     @staticmethod
     def backward(ctx, df):
-        x, acts, ws = ctx.x, ctx.acts, ctx.ws
+        x, *rest = ctx.saved_tensors
+        ws, acts = rest[:4], rest[4:]
         need = ctx.needs_input_grad
         grads = [None] * 9
         g = K.nhwc_flatten_bwd(_c(df), acts[3], Disc1TrunkFn.SLOPE)          # w.r.t. conv4's pre-activation
@@ -83,7 +86,6 @@ class Disc1TrunkFn(Function):
             grads[1], grads[2] = (dw if need[1] else None), db
         if need[0]:
             grads[0] = K.disc_stem_dgrad(g, _c(ws[0]), x.shape[2], x.shape[3])
-        ctx.acts = ctx.x = None
         return tuple(grads)
 
 
@@ -106,8 +108,8 @@ def _wide3x3(x, w, stride, pad, act, prec) -> bool:
 
 class Conv2dFn(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride: int, pad: int, act: int, prec=None):
-        prec = _prec() if prec is None else prec
+    def forward(ctx, x, w, bias, stride: int, pad: int, act: int, prec=None, layer: str = "other"):
+        prec = _prec(layer) if prec is None else prec
         if _wide3x3(x, w, stride, pad, act, prec):
             # one pixel-major bf16 copy of x serves the forward (16-byte patch staging, no gather / convert in the
             # kernel) and the weight gradient; only that copy is kept for the backward
@@ -143,19 +145,20 @@ class Conv2dFn(Function):
                 dw = K.conv3x3_wgrad_packed(dy16, x, H, W)
             if has_bias and ctx.needs_input_grad[2]:
                 db = K.channel_sum(dy)
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad, prec)
         if ctx.needs_input_grad[1]:
             dw = K.conv2d_wgrad(dy, x, w.shape[2], stride, pad, prec)
         if has_bias and ctx.needs_input_grad[2]:
             db = K.channel_sum(dy)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE, prec=None):
-    """``prec``: L.PREC_* override of the configured operand type (weight-space products stay exact fp32)"""
-    return Conv2dFn.apply(x, w, bias, stride, pad, act, prec)
+def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE, prec=None, layer="other"):
+    """``prec``: L.PREC_* override of the configured operand type (weight-space products stay exact fp32);
+    ``layer``: the layer class (config.LAYER_CLASSES) whose operand type applies otherwise"""
+    return Conv2dFn.apply(x, w, bias, stride, pad, act, prec, layer)
 
 
 class ActFn(Function):
@@ -219,7 +222,7 @@ class BnReluConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, w, bias, training, momentum, eps, pad):
-        prec = _prec()
+        prec = _prec("conv1x1" if w.shape[2] == 1 else "other")
         scale, shift, mean, invstd = _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps)
         y = K.conv2d_fwd(x, w, bias, 1, pad, prec, in_scale=scale, in_shift=shift, in_relu=True)
         ctx.save_for_backward(x, scale, shift, mean, invstd, w)
@@ -249,7 +252,7 @@ class DenseBlockFn(Function):
 
     @staticmethod
     def forward(ctx, x, training: bool, momentum: float, eps: float, *params):
-        prec = _prec()
+        prec = _prec("dense3x3")
         nl = len(params) // 6
         B, C0, H, W = x.shape
         g = params[4].shape[0]
@@ -328,7 +331,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
     N = H * W
     r = wq.shape[0]
     x3 = x.view(B, Cn, N)
-    fused = prec == L.PREC_BF16 and Cn <= 192 and r <= 31
+    fused = sixteen_bit("pam") and Cn <= 192 and r <= 31
     if fused and PAM_CAT and (bq is None) == (bk is None) == (bv is None):
         # q, k, v as ONE 1x1 conv over the concatenated weights: x is read once instead of three times
         wc = torch.empty(2 * r + Cn, Cn, 1, 1, device=x.device, dtype=torch.float32)
@@ -361,6 +364,7 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
         K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0, f16=f16,
                         k_sqmax=k_sqmax)
         return True, (qt, kt, kn, vt, o_attn, lse)
+    prec = prec if sixteen_bit("pam") else L.PREC_FP32     # the reference-shaped product chain below
     qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)
     s = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
     K.gemm_nt(B=B, M=N, N=N, kseg=1, klen=r, a=qt_, a_bs=N * r, a_ss=0, lda=r, bm=kt_, b_bs=N * r, b_ss=0,
@@ -413,6 +417,7 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
         qt_, kt_, v, p, o_attn = pam_saved
+        pprec = prec if sixteen_bit("pam") else L.PREC_FP32
         dop = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         K.copy_slab(d_pam, dop)
         dgamma_p = K.dot(dop, o_attn)
@@ -420,20 +425,20 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         dp = torch.empty(B, N, N, device=x.device, dtype=torch.float32)
         # dP[i][j] = sum_c dO'[c][i] V[c][j]
         K.conv_nn(B=B, M=N, Ck=Cn, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=dop,
-                  a_bs=Cn * N, a_sm=1, a_sc=N, a_st=0, x=v, x_bs=Cn * N, y=dp, y_bs=N * N, precision=prec)
+                  a_bs=Cn * N, a_sm=1, a_sc=N, a_st=0, x=v, x_bs=Cn * N, y=dp, y_bs=N * N, precision=pprec)
         ds = K.softmax_rows_bwd(p, dp, 1.0)
         del dp
         # dV[c][j] = sum_i dO'[c][i] P[i][j]
         dv = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         K.conv_nn(B=B, M=Cn, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=N, Ho=1, Wo=N, a=dop,
-                  a_bs=Cn * N, a_sm=N, a_sc=1, a_st=0, x=p, x_bs=N * N, y=dv, y_bs=Cn * N, precision=prec)
+                  a_bs=Cn * N, a_sm=N, a_sc=1, a_st=0, x=p, x_bs=N * N, y=dv, y_bs=Cn * N, precision=pprec)
         # dQt[i][d] = sum_j dS[i][j] Kt[j][d] ; dKt[j][d] = sum_i dS[i][j] Qt[i][d]
         dqt = torch.empty(B, N, r, device=x.device, dtype=torch.float32)
         dkt = torch.empty(B, N, r, device=x.device, dtype=torch.float32)
         K.conv_nn(B=B, M=N, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=r, Ho=1, Wo=r, a=ds,
-                  a_bs=N * N, a_sm=N, a_sc=1, a_st=0, x=kt_, x_bs=N * r, y=dqt, y_bs=N * r, precision=prec)
+                  a_bs=N * N, a_sm=N, a_sc=1, a_st=0, x=kt_, x_bs=N * r, y=dqt, y_bs=N * r, precision=pprec)
         K.conv_nn(B=B, M=N, Ck=N, ks=1, stride=1, pad=0, transposed=False, Hi=1, Wi=r, Ho=1, Wo=r, a=ds,
-                  a_bs=N * N, a_sm=1, a_sc=N, a_st=0, x=qt_, x_bs=N * r, y=dkt, y_bs=N * r, precision=prec)
+                  a_bs=N * N, a_sm=1, a_sc=N, a_st=0, x=qt_, x_bs=N * r, y=dkt, y_bs=N * r, precision=pprec)
         dq, dk = K.transpose(dqt), K.transpose(dkt)               # (B, r, N)
     grads = []
     for dy3, w, hb in ((dq, wq, has_bias[0]), (dk, wk, has_bias[1]), (dv, wv, has_bias[2])):
@@ -487,7 +492,7 @@ class PamFn(Function):
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma_p):
         x = _c(x)
-        prec = _prec()
+        prec = _prec("conv1x1")
         out = torch.empty_like(x)
         fused, saved = _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, _as3(out), prec)
         ctx.save_for_backward(x, wq, wk, wv, gamma_p, *saved)
@@ -513,7 +518,7 @@ class CamFn(Function):
     def forward(ctx, x, gamma_c):
         x = _c(x)
         out = torch.empty_like(x)
-        ctx.prec = _prec()
+        ctx.prec = _prec("cam_apply")
         att = _cam_forward(x, gamma_c, _as3(out), ctx.prec)
         ctx.save_for_backward(x, gamma_c, att)
         return out
@@ -537,25 +542,25 @@ class DualAttentionFn(Function):
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma_p, gamma_c):
         x = _c(x)
         B, Cn, H, W = x.shape
-        prec = _prec()
+        prec, cprec = _prec("conv1x1"), _prec("cam_apply")
         feats = torch.empty(B, 2 * Cn, H, W, device=x.device, dtype=torch.float32)
         fused, saved = _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, _as3(feats[:, :Cn]), prec)
-        att = _cam_forward(x, gamma_c, _as3(feats[:, Cn:]), prec)
+        att = _cam_forward(x, gamma_c, _as3(feats[:, Cn:]), cprec)
         ctx.save_for_backward(x, wq, wk, wv, gamma_p, gamma_c, att, *saved)
-        ctx.cfg = (prec, fused, (bq is not None, bk is not None, bv is not None))
+        ctx.cfg = (prec, fused, (bq is not None, bk is not None, bv is not None), cprec)
         return feats
 
     @staticmethod
     def backward(ctx, dfeat):
         x, wq, wk, wv, gamma_p, gamma_c, att, *saved = ctx.saved_tensors
-        prec, fused, has_bias = ctx.cfg
+        prec, fused, has_bias, cprec = ctx.cfg
         B, Cn, H, W = x.shape
         dfeat = _c(dfeat)
         d_pam, d_cam = _as3(dfeat[:, :Cn]), _as3(dfeat[:, Cn:])
         dx = torch.empty(B, Cn, H * W, device=x.device, dtype=torch.float32)
         K.copy_slab(d_pam, dx)                     # residual path of PAM
         K.copy_slab(d_cam, dx, accumulate=True)    # residual path of CAM
-        dgc = _cam_backward(att, x, gamma_c, d_cam, dx, prec)
+        dgc = _cam_backward(att, x, gamma_c, d_cam, dx, cprec)
         dwq, dbq, dwk, dbk, dwv, dbv, dgp = _pam_backward(fused, saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has_bias)
         return dx.view(B, Cn, H, W), dwq, dbq, dwk, dbk, dwv, dbv, dgp, dgc
 
@@ -629,7 +634,7 @@ class SkipFuseFn(Function):
 
     @staticmethod
     def forward(ctx, x, *wf):
-        prec = _prec()
+        prec = _prec("conv1x1")
         n = len(wf) // 2
         ws, fs = wf[:n], [_c(f) for f in wf[n:]]
         x = _c(x)
@@ -691,7 +696,7 @@ class MaxPool2Fn(Function):
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, act: int):
-        prec = _prec()
+        prec = _prec("disc")
         x = _c(x)
         Bn, Kin = x.shape
         Nout = w.shape[0]

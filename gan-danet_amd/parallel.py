@@ -22,14 +22,20 @@ element is unchanged.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+# GD_FORCE_COLLECTIVES=1: run every collective of the data-parallel path even in a ONE-rank world.  A one-GPU box cannot
+# host two RCCL ranks (RCCL refuses two ranks on one device), so this is how the "nccl" code paths -- reduce_scatter_tensor,
+# all_gather_into_tensor, the bucketed all-reduces -- execute on RCCL at all outside an 8-GPU node (tests/test_gpu_ddp.py).
+FORCE_COLLECTIVES = os.environ.get("GD_FORCE_COLLECTIVES", "0") == "1"
+
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def world_size() -> int:

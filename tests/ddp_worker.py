@@ -15,7 +15,12 @@ os.environ["MASTER_PORT"] = str(port)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("DDP_BACKEND", "gloo")
+if backend == "nccl":          # RCCL: one rank per device, so only world = 1 fits this box (GD_FORCE_COLLECTIVES=1)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 import gan_danet_amd as gd  # noqa: E402
 from fill import fill_module, seeded  # noqa: E402
 from gan_danet_amd.parallel import broadcast_module, shard_batch  # noqa: E402
@@ -41,10 +46,24 @@ with gd.precision(prec):
     tr = gd.GanTrainer(G, D, perceptual=None, shard_bytes=shard_bytes)   # built AFTER init_process_group: world = 2
     if shard_bytes:
         assert any(sp.p is D.fc1.weight for sp in tr.sharded), "fc1 should take the reduce-scatter / sharded-AdamW path"
+    if backend == "nccl" and shard_bytes:
+        # count the RCCL collectives that actually run
+        calls = {"rs": 0, "ag": 0, "ar": 0}
+        for nm, key in (("reduce_scatter_tensor", "rs"), ("all_gather_into_tensor", "ag"), ("all_reduce", "ar")):
+            orig = getattr(dist, nm)
+
+            def wrapped(*a, _o=orig, _k=key, **kw):
+                calls[_k] += 1
+                return _o(*a, **kw)
+            setattr(dist, nm, wrapped)
     sl = shard_batch(gb, world, rank)
     outs = [tr.step(x[sl], tgt[sl], 0.5) for _ in range(steps)]
 tr.sync_params()
 torch.cuda.synchronize()
+if backend == "nccl" and shard_bytes:
+    assert dist.get_backend() == "nccl"
+    assert calls["rs"] >= steps and calls["ag"] >= steps and calls["ar"] >= 2 * steps, calls
+    print("RCCL collectives executed:", calls, flush=True)
 if os.environ.get("DDP_SHARD_BYTES"):
     # the optimiser state of a sharded tensor is 1/world of it on each rank; state_dict() returns the full tensors
     st = tr.opt_d.state[D.fc1.weight]

@@ -184,3 +184,41 @@ def test_sharded_adamw_two_ranks_gloo(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_worker_sharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"sh_ok{r}").exists() for r in range(world))
+
+
+def _worker_early_stop(rank, world, port, tmpdir):
+    """EarlyStopping under data parallelism: the ranks see DIFFERENT shard losses; the save / count / stop
+    decisions must still be identical on every rank, so nobody sits in ``finish``'s barrier while the others run on"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gan_danet_amd.checkpoint import EarlyStopping
+    torch.manual_seed(0)
+    G = torch.nn.Linear(4, 4)
+    path = os.path.join(tmpdir, "best.pth")
+    es = EarlyStopping(patience=3, path=path)
+    # per-rank losses: rank 0 keeps "improving" on its own shard, rank 1 does not; the mean stops improving after epoch 1
+    seq = {0: [1.0, 0.9, 0.89, 0.88, 0.87, 0.86], 1: [1.0, 0.9, 1.1, 1.2, 1.3, 1.4]}[rank]
+    stops = []
+    for ep, loss in enumerate(seq):
+        stop = es.step(loss, G)
+        stops.append(stop)
+        t = torch.tensor([float(stop), es.best_loss, float(es.trigger_times)], dtype=torch.float64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        assert torch.equal(got[0], got[1]), f"epoch {ep}: ranks disagree {got}"
+        if stop:
+            break
+    assert stops == [False, False, False, False, True], stops     # mean 1.0, 0.9, 0.995, 1.04, 1.085 -> patience 3
+    assert abs(es.best_loss - 0.9) < 1e-12
+    open(os.path.join(tmpdir, f"es_ok{rank}"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_stopping_is_rank_uniform_two_ranks_gloo(tmp_path):
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_early_stop, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"es_ok{r}").exists() for r in range(world))

