@@ -180,6 +180,18 @@ __device__ __forceinline__ void mfma_v_first2x2(f32x16_t& d0, f32x16_t& d1, cons
             : "=&v"(d0), "=&v"(d1)
             : "v"(c), "v"(a0), "v"(b00), "v"(b10), "v"(a1), "v"(b01), "v"(b11));
 }
+// AGPR-form accumulate as asm: the dV^T steps of the hand-placed second half (schedule bit 5).  Source order is the
+// schedule; mfma_tie_a() pins VALU chunks between two MFMA pairs (no instruction: a dependency through the pair's
+// accumulators and the chunk's registers)
+template <bool F16>
+__device__ __forceinline__ void mfma_a_acc(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {
+    // volatile: hipcc otherwise sinks the last steps' MFMAs into the dK^T / dQ^T steps behind them
+    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_tie_a(f32x16_t& acc0, f32x16_t& acc1, f32x16_t& x) {
+    asm("" : "+a"(acc0), "+a"(acc1), "+v"(x));
+}
 template <bool NOPS>
 __device__ __forceinline__ void mfma_pad4(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) {
     if constexpr (NOPS) asm("s_nop 10" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -190,7 +202,8 @@ template <int CT, bool F16, int VREG, bool ATOMIC, int ORDER = 0>
 __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     const unsigned short* __restrict__ qt, const unsigned short* __restrict__ kt, const unsigned short* __restrict__ kn,
     const unsigned short* __restrict__ vt, const unsigned short* __restrict__ dot_, const float* __restrict__ rc,
-    int Npad, float* __restrict__ dkn, float* __restrict__ dv, void* __restrict__ dq_out, long dk_bs, long dv_bs) {
+    int Npad, float* __restrict__ dkn, float* __restrict__ dv, void* __restrict__ dq_out, long dk_bs, long dv_bs,
+    unsigned int* __restrict__ dbg) {
     constexpr int CP = CT * 32;
     constexpr int DOLD = CP + 32;                  // dO rows, chunk-swizzled (do_off)
     constexpr int DROWCH = DOLD / 8;               // 16-byte chunks per dO row
@@ -215,6 +228,27 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     // schedule variants (A/B switches, see the loop): bit 0 DQ_FIRST, bit 1 HANDOVER_MID, bit 2 DMA_LATE
     constexpr bool DQ_FIRST = (ORDER & 1) != 0, HANDOVER_MID = (ORDER & 2) != 0, DMA_LATE = (ORDER & 4) != 0;
     constexpr bool VFORM = (ORDER & 8) != 0;        // S / dP / dQ-part tiles through VGPR-form asm MFMAs
+    // bit 4: dS = P (dP - delta) as 32 single v_mul_f32 (asm) instead of the 16 v_pk_mul_f32 hipcc's SLP vectoriser makes
+    // of adjacent scalar multiplies -- packed f32 VALU issued while MFMAs are in flight is an anti-lever
+    // (MI355X_MICROARCH.md, "price of one filler beside MFMAs": one v_pk_fma_f32 = +22 cycles over two v_fma_f32)
+    constexpr bool NOPK = (ORDER & 16) != 0;
+    // bit 5: hand-placed second half -- the dS arithmetic (32 multiplies, 16 packs, the dS^T writes: a 50-instruction
+    // burst with the matrix pipe idle in the compiler's order) rides in the gaps of the first dV^T MFMA pairs, which only
+    // need P; the first transpose reads are requested before it
+    constexpr bool PH2 = (ORDER & 32) != 0;
+    static_assert(!PH2 || VFORM, "the hand-placed second half continues the hand-placed dP phase");
+    // bit 6 (diagnostic build only, tools/pam_stamps.py): s_memtime stamps at the segment seams of the tile loop; the
+    // values are requested without a wait (SMEM returns through lgkmcnt: the loop-top lgkmcnt(0) covers them) and summed
+    // per wave into dbg[(image, key block, wave)][8] = {wait+barrier, head, S+dP, dS, dV^T, dK^T+dQ^T, -, tiles}
+    constexpr bool STAMP = (ORDER & 64) != 0;
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned int sacc_t[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](auto ic) {
+        if constexpr (STAMP) {
+            unsigned long long& t = st[decltype(ic)::value];      // (a variable named only in an asm operand is not captured)
+            asm volatile("s_memtime %0" : "=s"(t));
+        }
+    };
     static_assert(!HANDOVER_MID || DQ_FIRST, "the mid-iteration hand-over follows the early dQ steps");
     static_assert(DCH % 64 == 0 && (OFF_X % 8) == 0 && (OFF_XQ % 8) == 0 && (OFF_V % 8) == 0, "LDS carve");
     static_assert((OFF_V + V_ELEMS) * 2 <= 163840, "LDS budget");
@@ -429,8 +463,20 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         // Younger VMEM operations than DMA(it): [hand-over(it-3)] DMA(it+1) [hand-over(it-2)]
         if (it < 2) wait_vmcnt<PPW>();
         else wait_vmcnt<PPW + 2 * AOPS>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
+        if constexpr (STAMP) {
+            // the previous iteration's stamps have landed behind this wait; st[0] = the end stamp of the iteration before it
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st[1]), "+s"(st[2]), "+s"(st[3]), "+s"(st[4]), "+s"(st[5]), "+s"(st[6]) :: "memory");
+            if (it > 1) {
+                sacc_t[0] += (unsigned int)(st[1] - st[0]);          // loop back + counted waits + barrier
+#pragma unroll
+                for (int k = 1; k < 6; ++k) sacc_t[k] += (unsigned int)(st[k + 1] - st[k]);
+            }
+            st[0] = st[6];
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
+        }
         __builtin_amdgcn_s_barrier();
+        stamp(IC<1>{});
         const int slot = it % NSLOT;
         // every LDS address below = (ring slot base) + (per-lane offset fixed for the whole sweep) + (compile-time
         // immediate): the XOR swizzle of the dO image only touches the low two chunk bits, so it folds into the
@@ -496,6 +542,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                     rcD[4 * g + e] = rc4[4 + g][e];
                 }
             mfma_v_first2x2<F16>(sacc[0], sacc[1], rcA, qa0, kfB[0][0], kfB[1][0], qa1, kfB[0][1], kfB[1][1]);
+            stamp(IC<2>{});
             if constexpr (DMA_LATE) {
                 dma_next(tpf, (it + 2) % NSLOT);
                 tpf = next_tile(tpf);
@@ -567,7 +614,9 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 if constexpr (s == (2 * CT > 4 ? 4 : 2 * CT - 1)) hq_commit(hq, tprev);
             });
             static_for<(2 * CT - 1 < 8 ? 2 * CT - 1 : 8), 8>(p_chunk);      // narrow C: the chunks no step was left for
-            mfma_pad<true>(dpacc[0], dpacc[1]);
+            // the wait states between the last dP MFMA and the first VALU read of dP; PH2 reads it two MFMAs later
+            mfma_pad<!PH2>(dpacc[0], dpacc[1]);
+            stamp(IC<3>{});
         } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -605,6 +654,20 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             }
         }
         }
+        // ---- second half: dV^T += dO^T P (CT steps), dK^T += Q^T dS (1 step), dQ^T part (2 steps) -------------------
+        // every A/B fragment below comes from a transpose read (element j of lane half h <-> query 16s + 8(j>>2) + 4h +
+        // (j&3)), issued one step (4 reads = both k-steps of one tile) ahead of the MFMAs that consume it.  Step ids:
+        // 0..CT-1 dV^T channel tile, CT dK^T, CT+1 / CT+2 dQ^T over the wave's key tile 0 / 1.
+        const unsigned int a_dlo = lds_addr(do_tr_lo), a_dhi = lds_addr(do_tr_hi);
+        const unsigned int a_q = lds_addr(q_tr), a_x = lds_addr(x_tr);
+        TrFrag2 fb[CT + 3];
+        auto issue = [&](auto idc) {
+            constexpr int id = decltype(idc)::value;
+            if constexpr (id < CT) fb[id] = tr_issue2<id * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
+            else if constexpr (id == CT) fb[id] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
+            else fb[id] = tr_issue2<(id - CT - 1) * 32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
+        };
+        if constexpr (PH2) issue(IC<0>{});             // dO^T of channel tile 0: in flight under the P hand-over below
         bf16x8_t pf[2][2], dsf[2][2];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -618,37 +681,36 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 pf[k2][1] = pack_frag<F16>(sacc[k2], 1);
             }
         }
+        // dS = P (dP - delta), its 16-bit pack and the dS^T image X[key][query] (this lane's 16 queries are 4 runs of 4),
+        // four accumulator registers at a time: chunk c = key tile c >> 2, registers 4 (c & 3) ..
+        u32x4_t dsw[2][2];
+        auto ds_chunk = [&](auto cc) {
+            constexpr int c = decltype(cc)::value, k2 = c >> 2, q = c & 3;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dpacc[k2][e] *= sacc[k2][e];               // dS = P (dP - delta)
-            dsf[k2][0] = pack_frag<F16>(dpacc[k2], 0);
-            dsf[k2][1] = pack_frag<F16>(dpacc[k2], 1);
-            // dS tile [query rows][key lanes] -> X[key][query] (this lane's 16 queries are 4 runs of 4)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const u32x4_t w = __builtin_bit_cast(u32x4_t, dsf[k2][s]);
-                const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
-                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * s) = lo;
-                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * s + 8) = hi;
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NOPK) {
+                    float t = dpacc[k2][4 * q + e];
+                    asm("v_mul_f32 %0, %0, %1" : "+v"(t) : "v"(sacc[k2][4 * q + e]));
+                    dpacc[k2][4 * q + e] = t;
+                } else {
+                    dpacc[k2][4 * q + e] *= sacc[k2][4 * q + e];
+                }
             }
-        }
-        // dV^T += dO^T P (CT steps), dK^T += Q^T dS (1 step), dQ^T part (2 steps): every A/B fragment below comes from
-        // a transpose read (element j of lane half h <-> query 16s + 8(j>>2) + 4h + (j&3)), issued one step (4 reads =
-        // both k-steps of one tile) ahead of the MFMAs that consume it.  Step ids: 0..CT-1 dV^T channel tile,
-        // CT dK^T, CT+1 / CT+2 dQ^T over the wave's key tile 0 / 1.
-        const unsigned int a_dlo = lds_addr(do_tr_lo), a_dhi = lds_addr(do_tr_hi);
-        const unsigned int a_q = lds_addr(q_tr), a_x = lds_addr(x_tr);
-        TrFrag2 fb[CT + 3];
+            dsw[k2][q >> 1][2 * (q & 1)] = pack2<F16>(dpacc[k2][4 * q], dpacc[k2][4 * q + 1]);
+            dsw[k2][q >> 1][2 * (q & 1) + 1] = pack2<F16>(dpacc[k2][4 * q + 2], dpacc[k2][4 * q + 3]);
+            if constexpr ((q & 1) == 1) {              // k-step q >> 1 of key tile k2 is complete
+                const u32x4_t w = dsw[k2][q >> 1];
+                const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
+                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * (q >> 1)) = lo;
+                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * (q >> 1) + 8) = hi;
+                dsf[k2][q >> 1] = __builtin_bit_cast(bf16x8_t, w);
+            }
+        };
+        if constexpr (!PH2) static_for<0, 8>(ds_chunk);
+        stamp(IC<4>{});
         f32x16_t dqp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqp[e] = 0.f;
-        auto issue = [&](auto idc) {
-            constexpr int id = decltype(idc)::value;
-            if constexpr (id < CT) fb[id] = tr_issue2<id * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
-            else if constexpr (id == CT) fb[id] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
-            else fb[id] = tr_issue2<(id - CT - 1) * 32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
-        };
         auto compute = [&](auto idc) {
             constexpr int id = decltype(idc)::value;
             const bf16x8_t a0 = tr_frag(fb[id].lo0, fb[id].hi0), a1 = tr_frag(fb[id].lo1, fb[id].hi1);
@@ -677,6 +739,45 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             }
         };
         constexpr int NSTEP = CT + 3;
+        if constexpr (PH2) {
+            // dV^T steps as asm MFMA pairs in source order = schedule; the eight dS chunks are spread over the gaps
+            // behind the pairs of the first steps (NCH per step, half behind each pair)
+            constexpr int NCH = (8 + CT - 1) / CT;
+            static_for<0, CT>([&](auto ic) {
+                constexpr int ct = decltype(ic)::value;
+                issue(IC<ct + 1>{});
+                tr_wait<4>(fb[ct]);
+                const bf16x8_t a0 = tr_frag(fb[ct].lo0, fb[ct].hi0), a1 = tr_frag(fb[ct].lo1, fb[ct].hi1);
+                mfma_a_acc<F16>(dvacc[0][ct], a0, pf[0][0]);
+                mfma_a_acc<F16>(dvacc[1][ct], a0, pf[1][0]);
+                static_for<0, (NCH + 1) / 2>([&](auto jc) {
+                    constexpr int c = ct * NCH + decltype(jc)::value;
+                    if constexpr (c < 8) {
+                        mfma_tie_a(dvacc[0][ct], dvacc[1][ct], dpacc[c >> 2]);
+                        ds_chunk(IC<c>{});
+                        mfma_tie_a(dvacc[0][ct], dvacc[1][ct], dpacc[c >> 2]);
+                    }
+                });
+                mfma_a_acc<F16>(dvacc[0][ct], a1, pf[0][1]);
+                mfma_a_acc<F16>(dvacc[1][ct], a1, pf[1][1]);
+                static_for<(NCH + 1) / 2, NCH>([&](auto jc) {
+                    constexpr int c = ct * NCH + decltype(jc)::value;
+                    if constexpr (c < 8) {
+                        mfma_tie_a(dvacc[0][ct], dvacc[1][ct], dpacc[c >> 2]);
+                        ds_chunk(IC<c>{});
+                        mfma_tie_a(dvacc[0][ct], dvacc[1][ct], dpacc[c >> 2]);
+                    }
+                });
+            });
+            stamp(IC<5>{});
+            static_for<CT, NSTEP>([&](auto ic) {
+                constexpr int id = decltype(ic)::value;
+                if constexpr (id + 1 < NSTEP) issue(IC<id + 1>{});
+                tr_wait<(id + 1 < NSTEP ? 4 : 0)>(fb[id]);
+                compute(IC<id>{});
+                if constexpr (id == CT + 2) xq_write();
+            });
+        } else {
         // DQ_FIRST: the dQ^T steps (and the exchange-buffer write) go in front of the dV^T / dK^T steps, so that the
         // iteration ends on independent MFMAs instead of a dependent chain + an LDS write in front of the barrier
         auto step_id = [](int i) constexpr { return DQ_FIRST ? (i < 2 ? CT + 1 + i : i - 2) : i; };
@@ -688,6 +789,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             constexpr int id = step_id(i);
             if constexpr (i + LA < NSTEP) issue(IC<step_id(i + LA)>{});
             constexpr int ahead = (NSTEP - 1 - i) < LA ? (NSTEP - 1 - i) : LA;      // steps whose reads are behind this one
+            if constexpr (i == CT) stamp(IC<5>{});
             tr_wait<4 * ahead>(fb[id]);
             compute(IC<id>{});
             if constexpr (id == CT + 2) {       // dQ^T part complete
@@ -695,12 +797,23 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 if constexpr (HANDOVER_MID) dq_handover((it + 1) & 1, tprev);
             }
         });
+        }
+        stamp(IC<6>{});
         tprev = tcur;
         tcur = next_tile(tcur);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     dq_handover((nqt + 1) & 1, tprev);
+    if constexpr (STAMP) {
+        if (dbg && lane == 0) {
+            unsigned int* o = dbg + (((long)b * gridDim.x + kb) * 4 + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = sacc_t[k];
+            o[6] = 0;
+            o[7] = (unsigned int)(nqt - 2);
+        }
+    }
 
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -731,7 +844,8 @@ template <int CT, bool F16, int VREG, bool ATOMIC>
 void launch_k64(dim3 grid, hipStream_t s, const unsigned short* q, const unsigned short* k, const unsigned short* kT,
                 const unsigned short* v, const unsigned short* dO, const float* rc, int Npad, float* dkn, float* dv,
                 void* dq_out, long dk_bs, long dv_bs) {
-    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC, 8>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out, dk_bs, dv_bs);
+    hipLaunchKernelGGL((pam_bwd_k64_kernel<CT, F16, VREG, ATOMIC, 8>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, dq_out, dk_bs, dv_bs,
+                       (unsigned int*)nullptr);
 }
 }  // namespace
 
@@ -740,10 +854,13 @@ extern "C" void gd_pam_dq_reduce_launch(const void* part, int KB, int Npad, int 
 // bench tooling: schedule variant of the K64 kernel (0 = production = VGPR-form S / dP tiles with the hand-placed
 // dP phase, 1 = the compiler-scheduled AGPR-form loop it replaced) and V-in-registers count (0 = default)
 static int g_k64_order = 0, g_k64_vreg = 0;
+static unsigned int* g_k64_dbg = nullptr;
 extern "C" void gd_pam_k64_variant(int order, int vreg) {
     g_k64_order = order;
     g_k64_vreg = vreg;
 }
+// diagnostic builds (variants 5, 6): per-wave cycle sums of the tile loop's segments, (images x key blocks x 4 waves x 8) words
+extern "C" void gd_pam_k64_debug(void* buf) { g_k64_dbg = (unsigned int*)buf; }
 
 // one batch slice through the 64-keys-per-wave backward; scratch holds `images` images' worth
 extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,
@@ -784,11 +901,17 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
     if (g_k64_order && Cp == 192 && !f16 && !deterministic) {     // schedule A/B variants (bench tooling only)
 #define K64_ORD(O_)                                                                                          \
     case O_:                                                                                                 \
-        if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs); \
-        else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs); \
+        if (vreg == 2) hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 2, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs, g_k64_dbg); \
+        else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs, g_k64_dbg); \
         break;
-        switch (g_k64_order == 1 ? 0 : -1) {      // variant 1 = the compiler-scheduled AGPR-form loop (ORDER 0)
-            K64_ORD(0)
+        switch (g_k64_order == 1 ? 0 : g_k64_order == 2 ? 24 : g_k64_order == 3 ? 56 : g_k64_order == 4 ? 8
+                : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : -1) {
+            K64_ORD(0)         // 1: the compiler-scheduled AGPR-form loop
+            K64_ORD(8)         // 4: round-2 production (hand-placed dP phase)
+            K64_ORD(24)        // 2: + unpacked dS multiplies
+            K64_ORD(56)        // 3: + hand-placed second half
+            K64_ORD(72)        // 5: production + segment stamps (diagnostic)
+            K64_ORD(120)       // 6: hand-placed second half + segment stamps (diagnostic)
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD

@@ -22,8 +22,17 @@ def probe(qt, kt, v, B_, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, **kw):
     ks = kw.get("k_sqmax")
     kmax = ks.sqrt() if ks is not None else kt.float()[..., :31].pow(2).sum(2).max(1).values.sqrt()
     bound = q2.sqrt().max(1).values * kmax
-    print(f"C={Cn}: max|q|(log2 units) {q2.sqrt().max().item():.2f}  max|k| {kmax.max().item():.2f}  bound {bound.max().item():.1f}",
-          flush=True)
+    # softmax over the keys is invariant under k_j -> k_j - kbar (a per-query shift q_i . kbar): the bound after
+    # centring the keys on their mean over the image (round 3: gd_pack_16 row_shift)
+    kf = kt.float()[:, :N, :31]
+    kc = kf - kf.mean(1, keepdim=True)
+    kcmax = kc.pow(2).sum(2).max(1).values.sqrt()
+    bound_c = q2.sqrt().max(1).values * kcmax
+    # per 256-query workgroup: the share of workgroups whose own bound passes (the kernel votes per workgroup)
+    qn = q2.sqrt()[:, :N].reshape(B_, -1, 256).max(2).values * kcmax[:, None]
+    print(f"C={Cn}: max|q|(log2 units) {q2.sqrt().max().item():.2f}  max|k| {kmax.max().item():.2f}  bound {bound.max().item():.1f}"
+          f"   centred keys: max|k - kbar| {kcmax.max().item():.2f}  bound {bound_c.max().item():.1f}  "
+          f"workgroups under 60: {(qn <= 60).float().mean().item():.3f}", flush=True)
     return orig(qt, kt, v, B_, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, **kw)
 
 
