@@ -12,9 +12,10 @@ gradients all-reduced with RCCL.  Prints ONE JSON line on rank 0.
 --config selects the other measured configurations of SURVEY.md 8d (default 3 = the metric's own):
     2   DANetAttention(64) FORWARD on a (B, 64, 128, 128) feature map, bf16 (attention bring-up; step = one forward)
     3/4 the full G+D step (4 = the same under torchrun with N ranks)
-    5   512x512 tiles, fp16 PAM operands, N = 262 144 tokens: generator forward + backward + AdamW (MSE + TV loss);
-        the discriminator is EXCLUDED (its fc1 alone is 8.6 G parameters = 137 GB with gradient and AdamW state) --
-        stated in config.workload
+    5   512x512 tiles, fp16 PAM operands, N = 262 144 tokens, batch 1 per GPU: the FULL G+D step like config 3.
+        Discriminator1.fc1 at this tile is 8.6e9 parameters: 34 GB of weights on every rank + 34 GB of gradient; the AdamW
+        state (69 GB) is whole at world 1 (~150 GB in all: fits 288 GB) and 1/world per rank under the sharded optimiser
+        (parallel.ShardedParam).  --no-disc gives round 2's generator-only variant (forward + backward + AdamW, MSE + TV).
 """
 from __future__ import annotations
 
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32", "mixed"])
     ap.add_argument("--no-perceptual", action="store_true", help="exploration only; the reported config has it on")
+    ap.add_argument("--no-disc", action="store_true", help="config 5 only: generator forward + backward + AdamW, no discriminator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -202,8 +204,8 @@ def main():
         workload = (f"DANetAttention({C2}) forward (PAM N={T * T} d_qk={C2 // 8} + CAM + fuse conv3x3/BN/ReLU) on "
                     f"({B},{C2},{T},{T}), batch {B}/GPU")
         metric = f"attention-forward samples/sec, DANetAttention(64) on {T}x{T}x64 feature maps"
-    elif cfg == 5:
-        # ---- BASELINE config 5: 512x512 tiles, fp16 PAM operands; G forward + backward + AdamW, D excluded ----
+    elif cfg == 5 and args.no_disc:
+        # ---- BASELINE config 5 without the discriminator: 512x512 tiles, fp16 PAM operands; G forward + backward + AdamW ----
         G = gd.FlexibleUpsamplingModule(input_channels=Cin).to(dev)
         G.apply(gd.weights_init_normal)
         for n, p in G.named_parameters():
@@ -261,6 +263,11 @@ def main():
             return last["out"].loss_g
         workload = (f"full G+D train step, {Cin}ch {T}x{T} -> {4 * T}x{4 * T} tiles, batch {B}/GPU (global {B * world}), "
                     f"perceptual={'on' if perc is not None else 'OFF'}, SSIM evaluated, AdamW x2")
+        if cfg == 5:
+            nfc1 = D.fc1.weight.numel()
+            workload += (f"; PAM N={T * T} tokens, fp16 MFMA operands in the fused PAM kernels (bf16 elsewhere); Discriminator1 "
+                         f"INCLUDED (fc1 {nfc1 / 1e9:.2f}e9 parameters: weights + gradient replicated, AdamW state "
+                         f"{'whole on this rank' if world == 1 else f'sharded 1/{world} per rank'})")
         metric = f"train samples/sec (G+D step) on {T}x{T} tiles"
 
     def sync():
@@ -285,11 +292,11 @@ def main():
         dt = tmax.item()
 
     finite = bool(torch.isfinite(res_t).all())
-    if cfg in (3, 4):
+    if cfg in (3, 4) or (cfg == 5 and not args.no_disc):
         out = last["out"]
         extra = {"loss_d": out.loss_d.item(), "loss_g": out.loss_g.item()}
         finite = finite and bool(torch.isfinite(out.loss_d).all())
-    elif cfg == 5:
+    elif cfg == 5 and args.no_disc:
         extra = {"loss": res_t.item()}
 
     # ---- roofline of the dominant kernel from the HIP-event brackets recorded around its launches ----

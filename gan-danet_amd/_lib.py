@@ -106,6 +106,7 @@ SIGNATURES = {
     "gd_pam_k64_variant": (None, [_i, _i]),
     "gd_pam_k64_debug": (None, [_p]),
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "gd_pam_f16_scale": (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "gd_conv3x3_nhwc_f32out": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p]),

@@ -368,6 +368,46 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__
     delta[(long)b * N + i] = s * (*gamma);
 }
 
+// ---- power-of-two scale of the PAM backward's fp16 operands ----------------------------------------------------
+// IEEE fp16 flushes |v| < 6e-8 and loses precision below 6e-5; gamma * dOut of a real training step sits far below that
+// (mean losses over 1e6..1e7 pixels).  Every output of the backward is linear in dOut, so dOut goes in as
+// gamma * 2^k * dOut with max |.| in [0.5, 1) and the consumers of dQ / dK / dV multiply by 2^-k (their alpha).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ a, long a_bs, long chw, float* __restrict__ ws) {
+    __shared__ float red[8];
+    const float* ap = a + (long)blockIdx.y * a_bs;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chw; i += (long)gridDim.x * 256) {
+        const float v = fabsf(ap[i]);
+        m = v > m ? v : m;                       // NaN never enters (comparison false): an all-NaN gradient scales by 1
+    }
+    m = gd_block_max(m, red);
+    if (threadIdx.x == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = m;
+}
+// scales[0] = gamma * 2^k, scales[1] = 2^-k with 2^k * |gamma| * amax in [0.5, 1); delta *= 2^k
+__global__ __launch_bounds__(256) void f16_scale_kernel(const float* __restrict__ ws, int nparts, const float* __restrict__ gamma,
+                                                       float* __restrict__ delta, long n, float* __restrict__ scales) {
+    __shared__ float red[8];
+    __shared__ float s_up;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, ws[i]);
+    m = gd_block_max(m, red);
+    if (threadIdx.x == 0) {
+        const float g = *gamma;
+        const float t = m * fabsf(g);
+        int e = 0;
+        if (t > 0.f && t < 3.0e38f) frexpf(t, &e);          // t = f * 2^e, f in [0.5, 1)
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        s_up = ldexpf(1.f, -e);
+        if (blockIdx.x == 0) {
+            scales[0] = g * s_up;
+            scales[1] = ldexpf(1.f, e);
+        }
+    }
+    __syncthreads();
+    const float up = s_up;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) delta[i] *= up;
+}
+
 // ---- losses --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, long n, float label, float inv_n,
                                                  float* __restrict__ dz, float* __restrict__ ws) {
@@ -781,6 +821,22 @@ extern "C" int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs,
     GD_CHECK_ARG(a && o && gamma && d_raw && delta && B > 0 && B <= 65535 && C > 0 && N > 0, "gd_chan_dot: bad arguments");
     hipLaunchKernelGGL(chan_dot_kernel, dim3(gd_cdiv(N, 256), B), dim3(256), 0, GD_S, a, a_bs, o, o_bs, C, N, gamma, d_raw,
                        delta);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gd_pam_f16_scale(const float* dout, long dout_bs, int B, int C, int N, const float* gamma, float* delta,
+                                float* scales, float* ws, void* stream) {
+    GD_CHECK_ARG(dout && gamma && delta && scales && ws && B > 0 && B <= 65535 && C > 0 && N > 0, "gd_pam_f16_scale: bad arguments");
+    const long chw = (long)C * N;
+    int g = grid_for(chw);
+    g = g > RED_BLOCKS / B ? RED_BLOCKS / B : g;
+    g = g < 1 ? 1 : g;
+    GD_CHECK_ARG((long)g * B <= RED_BLOCKS, "gd_pam_f16_scale: batch larger than the reduction workspace (1024 parts)");
+    hipLaunchKernelGGL(absmax_kernel, dim3(g, B), dim3(256), 0, GD_S, dout, dout_bs, chw, ws);
+    const long n = (long)B * N;
+    hipLaunchKernelGGL(f16_scale_kernel, dim3(grid_for(n) > 256 ? 256 : grid_for(n)), dim3(256), 0, GD_S, ws, g * B, gamma, delta, n,
+                       scales);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -215,18 +215,22 @@ def gemm_nt(*, B: int, M: int, N: int, kseg: int, klen: int, a: Tensor, a_bs: in
 
 
 def conv2d_wgrad(dy: Tensor, x: Tensor, k: int, stride: int, pad: int, precision: int, *, in_scale=None,
-                 in_shift=None, in_relu=False) -> Tensor:
-    """Gradient of nn.Conv2d w.r.t. its OIHW weight: dW[co][ci,kh,kw] = sum_{b,p} dy[b,co,p] x~[b,ci,p(+)tap]."""
+                 in_shift=None, in_relu=False, alpha: Optional[Tensor] = None) -> Tensor:
+    """Gradient of nn.Conv2d w.r.t. its OIHW weight: dW[co][ci,kh,kw] = sum_{b,p} dy[b,co,p] x~[b,ci,p(+)tap].
+    ``alpha`` (1x1 convs only): device scalar multiplying the result."""
+    if alpha is not None and not (k == 1 and stride == 1 and pad == 0):
+        raise L.GandanetError("conv2d_wgrad: alpha is supported for 1x1 convs only")
     dbs, xbs = _bview(dy, "wgrad dy"), _bview(x, "wgrad x")
     B, Cout, Ho, Wo = dy.shape
     _, Cin, Hi, Wi = x.shape
     dw = torch.empty(Cout, Cin, k, k, device=dy.device, dtype=torch.float32)
     with _ConvBracket("wgrad", k, stride, Cin, Cout, Ho, Wo, B):
         return _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu, dw, dbs, xbs, B, Cout, Cin, Hi,
-                             Wi, Ho, Wo)
+                             Wi, Ho, Wo, alpha)
 
 
-def _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu, dw, dbs, xbs, B, Cout, Cin, Hi, Wi, Ho, Wo):
+def _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu, dw, dbs, xbs, B, Cout, Cin, Hi, Wi, Ho, Wo,
+                  alpha=None):
     if USE_CONV3X3_FAST and k == 3 and stride in (1, 2) and pad == 1 and precision == L.PREC_BF16:
         dy16 = x16 = None
         x_ld = 0
@@ -247,7 +251,7 @@ def _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu,
         # BN affine (+ReLU) of the input is a per-row transform of the B operand
         gemm_nt(B=1, M=Cout, N=Cin, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0, b_ss=xbs,
                 ldb=Hi * Wi, c=dw, c_bs=0, ldc=Cin, precision=precision, in_scale=in_scale, in_shift=in_shift,
-                in_relu=in_relu)
+                in_relu=in_relu, alpha=alpha)
         return dw
     gemm_nt(B=1, M=Cout, N=Cin * k * k, kseg=B, klen=Ho * Wo, a=dy, a_bs=0, a_ss=dbs, lda=Ho * Wo, bm=x, b_bs=0,
             b_ss=xbs, ldb=0, c=dw, c_bs=0, ldc=Cin * k * k, precision=precision,
@@ -734,6 +738,18 @@ def chan_dot(a: Tensor, o: Tensor, gamma: Tensor):
     L.check(lib().gd_chan_dot(_ptr(a), abs_, _ptr(o), obs, B, Cn, N, _ptr(gamma), _ptr(d_raw), _ptr(delta), _stream()),
             "gd_chan_dot")
     return d_raw, delta
+
+
+def pam_f16_scale(dout: Tensor, gamma: Tensor, delta: Tensor) -> Tensor:
+    """power-of-two scale of the fp16 PAM backward (gd_pam_f16_scale): returns scales = [gamma * 2^k, 2^-k]; ``delta`` is
+    multiplied by 2^k in place"""
+    bs = _bview(dout, "dOut")
+    B, Cn = dout.shape[0], dout.shape[1]
+    N = dout[0, 0].numel()
+    scales = torch.empty(2, device=dout.device, dtype=torch.float32)
+    L.check(lib().gd_pam_f16_scale(_ptr(dout), bs, B, Cn, N, _ptr(gamma), _ptr(_dense(delta)), _ptr(scales),
+                                   _ptr(_red_ws(dout.device)), _stream()), "gd_pam_f16_scale")
+    return scales
 
 
 PAM_NOMAX = os.environ.get("GD_PAM_NOMAX", "1") != "0"      # let the forward drop the running maximum where a bound allows

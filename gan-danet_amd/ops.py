@@ -390,7 +390,13 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         d_raw, delta = K.chan_dot(d_pam, o_attn, gamma_p)
         dgamma_p = K.dot(d_raw, None)
         f16 = qt.dtype == torch.float16          # the operand type the forward packed
-        _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=gamma_p, t_shape=(Np, Cp), f16=f16)
+        s_up, s_inv = gamma_p, None
+        if f16:
+            # fp16 has no range for real training gradients (gamma * dOut ~ 1e-8): power-of-two scale in, 2^-k out
+            # through the alpha of the projection-gradient GEMMs (gd_pam_f16_scale; every output is linear in dOut)
+            scales = K.pam_f16_scale(d_pam, gamma_p, delta)
+            s_up, s_inv = scales[0:1], scales[1:2]
+        _, dot_ = K.pack_bf16(d_pam, Cn, N, scale=s_up, t_shape=(Np, Cp), f16=f16)
         if PAM_CAT and Np == N and K.pam_bwd_form() == L.PAM_BWD_K64_ATOMIC:
             # dq | dk | dv as row blocks of ONE buffer: the three projection data / weight / bias gradients below become
             # one GEMM each over it (dx read-modify-written once instead of three times, x read once)
@@ -402,9 +408,11 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
             for w_, lo in ((wq, 0), (wk, 32), (wv, 64)):
                 K.copy_slab(_c(w_).view(1, w_.shape[0], Cn), wcat.view(1, R, Cn)[:, lo:lo + w_.shape[0]])
             dcat4 = dcat.view(B, R, H, W)
-            dwc = K.conv2d_wgrad(dcat4, x, 1, 1, 0, prec)
+            dwc = K.conv2d_wgrad(dcat4, x, 1, 1, 0, prec, alpha=s_inv)
             dbc = K.channel_sum(dcat4) if any(has_bias) else None
-            K.conv2d_dgrad(dcat4, wcat, (H, W), 1, 0, prec, out=dx.view(B, Cn, H, W), accumulate=True)
+            if dbc is not None and s_inv is not None:
+                K.scale_dev(dbc, s_inv, out=dbc)
+            K.conv2d_dgrad(dcat4, wcat, (H, W), 1, 0, prec, out=dx.view(B, Cn, H, W), accumulate=True, alpha=s_inv)
             grads = []
             for (lo, n), hb in zip(((0, r), (32, r), (64, Cn)), has_bias):
                 grads.append(dwc[lo:lo + n])
@@ -414,6 +422,9 @@ def _pam_backward(fused, pam_saved, x, wq, wk, wv, gamma_p, d_pam, dx, prec, has
         dkn = torch.empty(B, 32, Np, device=x.device, dtype=torch.float32)
         dvp = torch.empty(B, Cp, Np, device=x.device, dtype=torch.float32)
         K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dqn, dkn, dvp, r_alg=r, c_alg=Cn, f16=f16)
+        if s_inv is not None:
+            for t in (dqn, dkn, dvp):
+                K.scale_dev(t, s_inv, out=t)
         dq, dk, dv = _compact(dqn, r, N), _compact(dkn, r, N), _compact(dvp, Cn, N)
     else:
         qt_, kt_, v, p, o_attn = pam_saved

@@ -391,6 +391,14 @@ int gd_chan_maxmean_bwd(const float* dy, const int* idx, float* dx, int B, int C
 /* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
 int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
                 float* d_raw, float* delta, void* stream);
+/* fp16 operand mode of gd_pam_flash_bwd (autograd of generator.py:115-122 under set_precision("fp16" | "mixed")): IEEE
+ * fp16 loses everything below 6e-8, and gamma * dOut of a real training step sits below that.  All outputs of the backward
+ * are linear in dOut, so it is packed as scales[0] * dOut with scales[0] = gamma * 2^k chosen so that the largest element has
+ * magnitude in [0.5, 1); delta (B, N), computed by gd_chan_dot with gamma, is multiplied by 2^k in place; the consumers of
+ * dQ / dK / dV multiply by scales[1] = 2^-k (the alpha of their GEMMs).  dout: (B, C, N) fp32, batch stride dout_bs;
+ * scales: 2 floats; ws: 1024 floats. */
+int gd_pam_f16_scale(const float* dout, long dout_bs, int B, int C, int N, const float* gamma, float* delta, float* scales,
+                     float* ws, void* stream);
 /* fp32 (B, R, Cc) planes (batch stride s_bs), times scale_imm and optionally times a device scalar -> bf16:
  *   plain      (B, Rp_plain, ld_plain)  zero padded copy          (NULL to skip)
  *   transposed (B, Ccp_t, ld_t)         zero padded transpose     (NULL to skip)

@@ -868,6 +868,112 @@ def test_pam_flash_backward_forms_agree_at_bench_and_max_size(gd):
                 assert all(torch.equal(a, b) for a, b in zip(got, again)), "K64 parts form must be bitwise reproducible"
 
 
+def test_pam_fp16_at_config5_size_properties(gd):
+    """BASELINE config 5's PAM -- N = 512 * 512 = 262 144 tokens, C = 184 (r = 23), IEEE fp16 MFMA operands -- where no
+    oracle can go (one N x N matrix = 275 GB): size-independent properties of the fp16 kernels.
+    forward : rows of P sum to 1 (V = const), linearity in V, all-equal keys -> mean of V;
+    backward: the two fp16 forms (fp32 atomics / fp16-free bf16 parts for dQ) agree; linearity in dOut; V = const ->
+              dQ = dK = 0 (dP is constant along a row, so dS = P (dP - delta) = 0); sum_j dK_j = 0 (rows of dS sum to
+              zero: the reason key.bias has an analytically zero gradient); fp16 and bf16 operands agree at 16-bit level."""
+    from gan_danet_amd import kern as K
+    from gan_danet_amd import _lib as L
+    B, C, side = 1, 184, 512
+    N, r = side * side, C // 8
+    Np, Cp = N, 192
+    ones = Cp - 1
+    g = torch.Generator(device=DEV).manual_seed(17)
+    q = torch.randn(B, r, N, device=DEV, generator=g) * 0.5
+    k = torch.randn(B, r, N, device=DEV, generator=g) * 0.5
+    v1 = torch.randn(B, C, N, device=DEV, generator=g)
+    v2 = torch.randn(B, C, N, device=DEV, generator=g)
+    do1 = torch.randn(B, C, N, device=DEV, generator=g)
+    do2 = torch.randn(B, C, N, device=DEV, generator=g)
+    gamma = torch.full((1,), 0.5, device=DEV)
+    x0 = torch.zeros(B, C, N, device=DEV)
+
+    def fwd(qq, kk, vv, f16=True):
+        _, qt = K.pack_bf16(qq, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32), f16=f16)
+        kn, kt = K.pack_bf16(kk, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31, f16=f16)
+        vn, vt = K.pack_bf16(vv, C, N, plain_shape=(Cp, Np), t_shape=(Np, Cp), perm16=True, ones_row=ones, f16=f16)
+        out, o, lse = torch.empty(B, C, N, device=DEV), torch.empty(B, C, N, device=DEV), torch.empty(B, N, device=DEV)
+        K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x0, out, o, lse, r_alg=r, v_ones=True, f16=f16)
+        return (qt, kt, kn, vt), o, lse
+
+    def bwd(packs, o, lse, do, form, f16=True):
+        qt, kt, kn, vt = packs
+        _, delta = K.chan_dot(do, o, gamma)
+        _, dot_ = K.pack_bf16(do, C, N, scale=gamma, t_shape=(Np, Cp), f16=f16)
+        dq = torch.full((B, 32, Np), float("nan"), device=DEV)
+        dk = torch.full((B, 32, Np), float("nan"), device=DEV)
+        dv = torch.full((B, Cp, Np), float("nan"), device=DEV)
+        K.pam_flash_bwd(qt, kt, kn, vt, dot_, lse, delta, B, N, Np, Cp, dq, dk, dv, r_alg=r, c_alg=C, f16=f16, form=form)
+        return dq[:, :r, :N].clone(), dk[:, :r, :N].clone(), dv[:, :C, :N].clone()
+
+    # ---- forward ----
+    const = torch.full((B, C, N), 0.75, device=DEV)
+    _, oc, _ = fwd(q, k, const)
+    assert_close(oc, const.cpu(), 2e-3, "row sums (fp16, N = 262144)")
+    p1, o1, lse1 = fwd(q, k, v1)
+    _, o2, _ = fwd(q, k, v2)
+    _, o12, _ = fwd(q, k, v1 + v2)
+    assert_close(o12, (o1 + o2).cpu(), 5e-3, "linearity in V", rell2)
+    _, ou, _ = fwd(q, torch.ones(B, r, N, device=DEV), v1)
+    mean_v = v1.to(torch.float16).float().mean(dim=2, keepdim=True).expand(B, C, N)
+    assert_close(ou, mean_v.cpu(), 2e-2, "uniform attention = mean of V", rell2)
+    # ---- backward ----
+    a = bwd(p1, o1, lse1, do1, L.PAM_BWD_K64_ATOMIC)
+    b_ = bwd(p1, o1, lse1, do2, L.PAM_BWD_K64_ATOMIC)
+    ab = bwd(p1, o1, lse1, do1 + do2, L.PAM_BWD_K64_ATOMIC)
+    for n_, x_, y_, z_ in zip(("dQ", "dK", "dV"), a, b_, ab):
+        assert torch.isfinite(z_).all()
+        assert_close(z_, (x_ + y_).cpu(), 1e-2, f"{n_}: linearity in dOut", rell2)
+    parts = bwd(p1, o1, lse1, do1, L.PAM_BWD_K64_PARTS)
+    assert_close(parts[1], a[1].cpu(), 1e-5, "dK atomic vs parts", rell2)
+    assert_close(parts[2], a[2].cpu(), 1e-5, "dV atomic vs parts", rell2)
+    assert_close(parts[0], a[0].cpu(), 1e-2, "dQ atomic vs bf16 parts", rell2)
+    sum_dk = a[1].double().sum(dim=2)                        # (B, r): analytically zero
+    assert (sum_dk.abs().max() / (a[1].double().abs().sum(dim=2).max() + 1e-30)).item() <= 2e-3, "sum_j dK_j != 0"
+    pc, ocn, lsec = fwd(q, k, const)
+    dqc, dkc, dvc = bwd(pc, ocn, lsec, do1, L.PAM_BWD_K64_ATOMIC)
+    scale = a[0].abs().max().item()
+    assert dqc.abs().max().item() <= 2e-2 * scale and dkc.abs().max().item() <= 2e-2 * a[1].abs().max().item(), \
+        "V = const must give dQ = dK = 0"
+    # fp16 vs bf16 operands on the same inputs
+    pb, ob, lseb = fwd(q, k, v1, f16=False)
+    bb = bwd(pb, ob, lseb, do1, L.PAM_BWD_K64_ATOMIC, f16=False)
+    assert_close(ob, o1.cpu(), 1e-2, "O fp16 vs bf16", rell2)
+    for n_, x_, y_ in zip(("dQ", "dK", "dV"), a, bb):
+        assert_close(x_, y_.cpu(), 2e-2, f"{n_} fp16 vs bf16", rell2)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "mixed"])
+def test_pam_fp16_backward_survives_tiny_gradients(gd, prec):
+    """fp16 has no range for real training gradients: a mean loss over 1e6 pixels puts gamma * dOut around 1e-9, below
+    fp16's smallest subnormal (6e-8).  The backward scales dOut by a power of two on the way in and the projection
+    gradients by its inverse on the way out (gd_pam_f16_scale): an upstream gradient of 1e-9 x randn must give 1e-9 x
+    the gradients of randn (bit-for-bit up to the power of two when the factor is one: here 2^-30)."""
+    from gan_danet_amd.generator import PAMModule
+    m = PAMModule(64)
+    fill_module(m)
+    with torch.no_grad():
+        m.gamma.fill_(0.3)
+    m.to(DEV)
+    x = seeded((2, 64, 16, 16), 41)
+    go = seeded((2, 64, 16, 16), 42)
+    res = []
+    for s in (1.0, 2.0 ** -30):
+        for p in m.parameters():
+            p.grad = None
+        xd = x.to(DEV).requires_grad_(True)
+        with gd.precision(prec):
+            y = m(xd)
+            y.backward((go * s).to(DEV))
+        res.append((xd.grad.clone(), m.value.weight.grad.clone(), m.query.weight.grad.clone()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert b_.abs().max().item() > 0, "gradient flushed to zero"
+        assert_close(b_ * 2.0 ** 30, a_.cpu(), 1e-5, "scaled gradient", rell2)
+
+
 def test_inference_tile_180x88_and_postprocessing(gd):
     """f3: the 0.05-degree inference call of test.ipynb (c1:149-167) -- eval-mode generator on a batch of FOUR 180 x 88
     tiles (PAM over N = 15 840 tokens, ragged against every tile size of the kernels), bicubic x1.25, the x4 bicubic of
