@@ -63,7 +63,9 @@ SIGNATURES = {
     "gd_conv3x3_ws_bytes": (_sz, [_i, _i]),
     "gd_conv3x3_eligible": (_i, [C.POINTER(ConvDesc)]),
     "gd_conv3x3": (_i, [C.POINTER(ConvDesc), _p, _sz, _p]),
-    "gd_conv3x3_wgrad": (_i, [_p, _l, _p, _p, _l, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "gd_conv3x3_wgrad": (_i, [_p, _l, _p, _p, _l, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "gd_pack_16_split": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _p, _l, _i, _l, _i, _i, _p, _l, _i, _l, _i, _i, _p]),
+    "gd_split3_weights": (_i, [_p, _l, _l, _l, _p, _p]),
     "gd_bn_stats_ws_floats": (_sz, [_i, _i, _l]),
     "gd_bn_stats": (_i, [_p, _l, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
     "gd_bn_fold": (_i, [_p, _p, _p, _p, _i, _p, _p, _p]),

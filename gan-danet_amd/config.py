@@ -7,8 +7,10 @@ from typing import Dict
 
 PRECISIONS = ("bf16", "fp16", "fp32", "mixed")
 
-# layer classes whose operand type can be overridden one at a time (tools/parity_report.py: error attribution)
-LAYER_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "pam", "stem", "disc", "vgg")
+# layer classes whose operand type can be overridden one at a time (tools/parity_attribution.py: error attribution)
+LAYER_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "pam", "stem", "disc", "vgg", "other")
+# classes served by the split-bf16 ("x3") route of the pixel-major 3x3 kernels under "mixed"; the others run exact f32 MFMA
+X3_CLASSES = ("dense3x3", "fuse3x3", "decoder", "vgg")
 
 
 @dataclass
@@ -23,7 +25,7 @@ class _Config:
     #           accumulate / softmax statistics) and every other product in split-bf16 ("x3": hi*hi + lo*hi + hi*lo,
     #           2^-16 relative) or exact f32 MFMA.
     precision: str = "bf16"
-    # per-layer-class override {class: "exact" | "16"} on top of ``precision`` (attribution runs only)
+    # per-layer-class override {class: "exact" | "x3" | "16"} on top of ``precision`` (attribution runs only)
     override: Dict[str, str] = field(default_factory=dict)
 
 
@@ -50,7 +52,7 @@ def precision(p: str):
 def layer_override(**kw: str):
     """``layer_override(dense3x3="exact")``: run one layer class exact (or 16-bit) whatever the configured mode"""
     for k, v in kw.items():
-        if k not in LAYER_CLASSES or v not in ("exact", "16"):
+        if k not in LAYER_CLASSES or v not in ("exact", "x3", "16"):
             raise ValueError(f"layer_override: {k}={v}")
     old = dict(config.override)
     config.override.update(kw)
@@ -60,11 +62,21 @@ def layer_override(**kw: str):
         config.override = old
 
 
-def sixteen_bit(layer: str) -> bool:
-    """does this layer class run on 16-bit MFMA operands right now?"""
+def operand_mode(layer: str) -> str:
+    """"16" (plain 16-bit MFMA operands), "x3" (split-bf16: hi*hi + lo*hi + hi*lo, ~2^-16 relative) or "exact" (f32 MFMA)
+    for a layer class right now"""
     o = config.override.get(layer)
     if o is not None:
-        return o == "16"
+        return o
     if layer == "pam":
-        return config.precision != "fp32"
-    return config.precision in ("bf16", "fp16")
+        return "exact" if config.precision == "fp32" else "16"
+    if config.precision in ("bf16", "fp16"):
+        return "16"
+    if config.precision == "mixed" and layer in X3_CLASSES:
+        return "x3"
+    return "exact"
+
+
+def sixteen_bit(layer: str) -> bool:
+    """does this layer class run on plain 16-bit MFMA operands right now?"""
+    return operand_mode(layer) == "16"

@@ -987,17 +987,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
 }  // namespace
 
-// dw (Cout, Cin, 3, 3) fp32 is overwritten.  Same input-transform contract as gd_conv2d.
+// dw (Cout, Cin, 3, 3) fp32 is overwritten (accumulate = 0) or added to.  Same input-transform contract as gd_conv2d.
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
                                 const void* x_nhwc16, int x_ld, const float* in_scale, const float* in_shift, int in_relu,
-                                int B, int Cout, int Cin, int H, int W, int stride, float* dw, void* stream) {
+                                int B, int Cout, int Cin, int H, int W, int stride, int accumulate, float* dw, void* stream) {
     GD_CHECK_ARG((dy || dy_bf16) && (x || x_nhwc16) && dw, "gd_conv3x3_wgrad: null pointer");
     GD_CHECK_ARG(!x_nhwc16 || (!in_scale && x_ld >= Cin && x_ld % 8 == 0),
                  "gd_conv3x3_wgrad: the pixel-major bf16 x needs x_ld >= Cin, x_ld % 8 == 0 and no input transform");
     GD_CHECK_ARG(B > 0 && Cout > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gd_conv3x3_wgrad: bad sizes");
     GD_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gd_conv3x3_wgrad: in_scale/in_shift must come together");
     hipStream_t s = (hipStream_t)stream;
-    GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) == hipSuccess, "gd_conv3x3_wgrad: memset failed");
+    // the pixel splits add into dw with fp32 atomics: it starts from zero, or (accumulate) from what it holds
+    if (!accumulate)
+        GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), s) == hipSuccess, "gd_conv3x3_wgrad: memset failed");
     WgradArgs a;
     a.dy16 = (const unsigned short*)dy_bf16;
     a.dy = dy; a.dy_bs = dy_bs; a.x = x; a.x_bs = x_bs;

@@ -272,6 +272,102 @@ __global__ __launch_bounds__(256) void pack16_tile64_kernel(const float* __restr
     }
 }
 
+// ---- split-bf16 ("x3") operands --------------------------------------------------------------------------------------
+// set_precision("mixed") keeps the convolutions at ~2^-16 relative error on the bf16 matrix pipe: every operand is split
+// v = hi + lo (hi = bf16(v), lo = bf16(v - hi)) and a product runs as hi*hi + lo*hi + hi*lo -- three bf16 MFMAs with fp32
+// accumulation, 5x the rate of the exact f32 MFMA.  The split rides in the operand LAYOUT, so the conv kernels are the
+// plain 16-bit ones: the activation pack below writes up to three copies of the tile, each holding the hi or the lo part
+// (copy j at `cs` elements behind copy j - 1; bit j of `pattern` set = lo), e.g. pixel-major [hi | lo | hi] as 3 C
+// channels for the forward / data gradient against the weights [hi ; hi ; lo] (gd_split3_weights), or separate hi / lo
+// images for the weight gradient's three accumulating launches.  Same 64 x 64 tiling, per-row affine + ReLU and
+// alignment contract as pack16_tile64_kernel (Cc % 4 == 0, leading dimensions % 8 == 0); bf16 only.
+__global__ __launch_bounds__(256) void pack16_split_kernel(const float* __restrict__ s, long s_bs, int R, int Cc,
+                                                          const float* __restrict__ row_scale,
+                                                          const float* __restrict__ row_shift, int relu,
+                                                          unsigned short* __restrict__ plain, long p_bs, int ldp, long p_cs,
+                                                          int p_n, int p_pat, unsigned short* __restrict__ tr, long t_bs,
+                                                          int ldt, long t_cs, int t_n, int t_pat) {
+    constexpr int TLD = 72;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[2][64 * TLD];      // [0] hi, [1] lo
+    const int b = blockIdx.z;
+    const float* sp = s + (long)b * s_bs;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    {
+        const int cg = (tid & 15) * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int rl = (tid >> 4) + 16 * kk;
+            const int r = r0 + rl, c = c0 + cg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R && c < Cc) {
+                v = *reinterpret_cast<const float4*>(sp + (long)r * Cc + c);
+                if (row_scale) {
+                    const float a = row_scale[r], sh = row_shift[r];
+                    v.x = fmaf(v.x, a, sh); v.y = fmaf(v.y, a, sh); v.z = fmaf(v.z, a, sh); v.w = fmaf(v.w, a, sh);
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            uint2 hi;
+            hi.x = gd_pack_bf2(v.x, v.y);
+            hi.y = gd_pack_bf2(v.z, v.w);
+            uint2 lo;
+            lo.x = gd_pack_bf2(v.x - gd_bf2f((unsigned short)(hi.x & 0xFFFFu)), v.y - gd_bf2f((unsigned short)(hi.x >> 16)));
+            lo.y = gd_pack_bf2(v.z - gd_bf2f((unsigned short)(hi.y & 0xFFFFu)), v.w - gd_bf2f((unsigned short)(hi.y >> 16)));
+            *reinterpret_cast<uint2*>(tile[0] + rl * TLD + cg) = hi;
+            *reinterpret_cast<uint2*>(tile[1] + rl * TLD + cg) = lo;
+        }
+    }
+    __syncthreads();
+    if (plain) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int it = tid + 256 * kk;
+            const int rl = it >> 3, g = it & 7;
+            const int r = r0 + rl, c = c0 + 8 * g;
+            if (r < R && c < ldp) {
+                for (int j = 0; j < p_n; ++j) {
+                    const uint4 o = *reinterpret_cast<const uint4*>(tile[(p_pat >> j) & 1] + rl * TLD + 8 * g);
+                    *reinterpret_cast<uint4*>(plain + (long)j * p_cs + (long)b * p_bs + (long)r * ldp + c) = o;
+                }
+            }
+        }
+    }
+    if (tr) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int it = tid + 256 * kk;
+            const int cl = it >> 3, rg = (it & 7) * 8;
+            const int c = c0 + cl, r = r0 + rg;
+            if (c < Cc && r < R) {                       // R % 8 == 0 (checked by the host): 8 rows are all in or all out
+                for (int j = 0; j < t_n; ++j) {
+                    const unsigned short* tl = tile[(t_pat >> j) & 1];
+                    unsigned int w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        w[q] = (unsigned int)tl[(rg + 2 * q) * TLD + cl] | ((unsigned int)tl[(rg + 2 * q + 1) * TLD + cl] << 16);
+                    *reinterpret_cast<uint4*>(tr + (long)j * t_cs + (long)b * t_bs + (long)c * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    }
+}
+// w (A, Bn, Cn) fp32 -> out (A, 3 Bn, Cn) fp32: [hi ; hi ; lo] along the middle axis (hi = the bf16 rounding of w as a
+// float, lo = w - hi: exact in fp32; the 16-bit weight pack then rounds lo to bf16)
+__global__ __launch_bounds__(256) void split3_weights_kernel(const float* __restrict__ w, long A, long Bn, long Cn,
+                                                            float* __restrict__ out) {
+    const long total = A * Bn * Cn;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long a = i / (Bn * Cn), rem = i - a * (Bn * Cn);
+        const float v = w[i];
+        const float hi = gd_bf2f((unsigned short)(gd_pack_bf2(v, 0.f) & 0xFFFFu));
+        float* o = out + a * 3 * Bn * Cn + rem;
+        o[0] = hi;
+        o[Bn * Cn] = hi;
+        o[2 * Bn * Cn] = v - hi;
+    }
+}
+
 // ---- CustomDataset.apply_augmentation (datasets.py:181-208) as one gather -------------------------------------------
 // op word of a sample: bit 0 horizontal flip, bit 1 vertical flip, bits 2-3 number of 90-degree turns (torch.rot90,
 // dims [1, 2]), bit 4 additive noise.  The three geometric steps compose to one index map; tiles are square when
@@ -771,6 +867,33 @@ extern "C" int gd_pack_16_affine(const float* s, long s_bs, int B, int R, int Cc
     hipLaunchKernelGGL(pack16_tile64_kernel, dim3(gd_cdiv(cols, 64), gd_cdiv(rows, 64), B), dim3(256), 0, GD_S, s, s_bs, R, Cc,
                        (const float*)nullptr, 1.f, row_scale, row_shift, relu, (unsigned short*)plain, Rp_plain, ld_plain,
                        (unsigned short*)transposed, Ccp_t, ld_t, 0, -1, f16);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+// split-bf16 pack (see pack16_split_kernel).  plain: copies of the (R, Cc) tile as rows of length ldp (channel-major),
+// tr: copies of its transpose as rows of length ldt (pixel-major); image b of copy j at ptr + j * cs + b * bs; copy j
+// holds the lo part when bit j of the pattern is set, else the hi part.  Pad columns beyond the data are NOT written.
+extern "C" int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
+                                int relu, void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr,
+                                long t_bs, int ldt, long t_cs, int t_ncopy, int t_pattern, void* stream) {
+    GD_CHECK_ARG(s && (plain || tr) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_16_split: bad arguments");
+    GD_CHECK_ARG((row_scale == nullptr) == (row_shift == nullptr), "gd_pack_16_split: row_scale / row_shift come together");
+    GD_CHECK_ARG(Cc % 8 == 0 && R % 8 == 0 && s_bs % 4 == 0 && ((uintptr_t)s % 16) == 0, "gd_pack_16_split: R, Cc must be multiples of 8");
+    GD_CHECK_ARG(!plain || (ldp == Cc && p_ncopy >= 1 && p_ncopy <= 3 && p_cs % 8 == 0 && p_bs % 8 == 0 && (uintptr_t)plain % 16 == 0),
+                 "gd_pack_16_split: plain output needs ldp == Cc, 1..3 copies, 16-byte aligned strides");
+    GD_CHECK_ARG(!tr || (ldt >= R && ldt % 8 == 0 && t_ncopy >= 1 && t_ncopy <= 3 && t_cs % 8 == 0 && t_bs % 8 == 0 && (uintptr_t)tr % 16 == 0),
+                 "gd_pack_16_split: transposed output needs ldt >= R, ldt % 8 == 0, 1..3 copies, 16-byte aligned strides");
+    GD_CHECK_ARG(gd_cdiv(R, 64) <= 65535, "gd_pack_16_split: too many rows");
+    hipLaunchKernelGGL(pack16_split_kernel, dim3(gd_cdiv(Cc, 64), gd_cdiv(R, 64), B), dim3(256), 0, GD_S, s, s_bs, R, Cc, row_scale,
+                       row_shift, relu, (unsigned short*)plain, p_bs, ldp, p_cs, p_ncopy, p_pattern, (unsigned short*)tr, t_bs, ldt,
+                       t_cs, t_ncopy, t_pattern);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_split3_weights(const float* w, long A, long Bn, long Cn, float* out, void* stream) {
+    GD_CHECK_ARG(w && out && A > 0 && Bn > 0 && Cn > 0, "gd_split3_weights: bad arguments");
+    const long total = A * Bn * Cn;
+    hipLaunchKernelGGL(split3_weights_kernel, dim3(grid_for(total) > 4096 ? 4096 : grid_for(total)), dim3(256), 0, GD_S, w, A, Bn, Cn, out);
     GD_LAUNCH_CHECK();
     return 0;
 }

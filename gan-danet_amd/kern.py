@@ -243,7 +243,7 @@ def _conv2d_wgrad(dy, x, k, stride, pad, precision, in_scale, in_shift, in_relu,
                 x_ld = (Cin + 7) // 8 * 8
                 _, x16 = pack_bf16(x, Cin, Hi * Wi, t_shape=(Hi * Wi, x_ld))
         L.check(lib().gd_conv3x3_wgrad(_ptr(dy), dbs, _ptr(dy16), _ptr(x), xbs, _ptr(x16), x_ld, _ptr(in_scale),
-                                       _ptr(in_shift), int(in_relu), B, Cout, Cin, Hi, Wi, stride, _ptr(dw), _stream()),
+                                       _ptr(in_shift), int(in_relu), B, Cout, Cin, Hi, Wi, stride, 0, _ptr(dw), _stream()),
                 "gd_conv3x3_wgrad")
         return dw
     if k == 1 and stride == 1 and pad == 0:
@@ -871,7 +871,57 @@ def conv3x3_wgrad_packed(dy16: Tensor, x16: Tensor, H: int, W: int, stride: int 
     dw = torch.empty(Cout, Cin, 3, 3, device=dy16.device, dtype=torch.float32)
     with _ConvBracket("wgrad_packed", 3, stride, Cin, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, B):
         L.check(lib().gd_conv3x3_wgrad(None, 0, _ptr(dy16), None, 0, _ptr(x16), Cin, None, None, 0, B, Cout, Cin, H, W, stride,
-                                       _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+                                       0, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+    return dw
+
+
+# ---- split-bf16 ("x3") operands: set_precision("mixed") -------------------------------------------------------------
+HLH, HL, H_ONLY = 0b010, 0b10, 0b0      # copy patterns of pack_split: bit j set = copy j holds the lo part
+
+
+def pack_split(x: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, relu: bool = False,
+               want_plain: bool = False, want_tr: bool = True):
+    """(B, C, H, W) / (B, C, N) fp32 (per-image dense) -> split-bf16 copies (gd_pack_16_split):
+    tr    (B, N, 3 C) pixel-major [hi | lo | hi]: the forward / data-gradient operand against gd_split3_weights
+    plain (2, B, C, N) channel-major, [0] hi and [1] lo: the dY operand of the weight gradient's three launches"""
+    sbs = _bview(x, "pack input")
+    B, Cn = x.shape[0], x.shape[1]
+    N = x[0, 0].numel()
+    plain = torch.empty(2, B, Cn, N, device=x.device, dtype=torch.bfloat16) if want_plain else None
+    tr = torch.empty(B, N, 3 * Cn, device=x.device, dtype=torch.bfloat16) if want_tr else None
+    L.check(lib().gd_pack_16_split(_ptr(x), sbs, B, Cn, N, _ptr(scale), _ptr(shift), int(relu),
+                                   _ptr(plain), Cn * N, N, B * Cn * N, 2, HL,
+                                   _ptr(tr), N * 3 * Cn, 3 * Cn, Cn, 3, HLH, _stream()), "gd_pack_16_split")
+    return plain, tr
+
+
+def split3_weights(w: Tensor, axis: int) -> Tensor:
+    """(Cout, Cin, k, k) fp32 -> [hi ; hi ; lo] along ``axis`` (1: input channels, forward; 0: output channels, the
+    data gradient's contraction axis)"""
+    _dense(w, "conv weight")
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    if axis == 1:
+        out = torch.empty(Cout, 3 * Cin, *w.shape[2:], device=w.device, dtype=torch.float32)
+        L.check(lib().gd_split3_weights(_ptr(w), Cout, Cin, taps, _ptr(out), _stream()), "gd_split3_weights")
+    else:
+        out = torch.empty(3 * Cout, Cin, *w.shape[2:], device=w.device, dtype=torch.float32)
+        L.check(lib().gd_split3_weights(_ptr(w), 1, Cout, Cin * taps, _ptr(out), _stream()), "gd_split3_weights")
+    return out
+
+
+def conv3x3_wgrad_x3(dy2: Tensor, x3: Tensor, H: int, W: int) -> Tensor:
+    """weight gradient from split operands: dy2 (2, B, Cout, N) [hi, lo] channel-major, x3 (B, N, 3 Cin) [hi | lo | hi]
+    pixel-major (the forward's own pack): dW = dy_hi (x) x_hi + dy_lo (x) x_hi + dy_hi (x) x_lo, three launches adding
+    into one dW"""
+    _bf(dy2, "dy2"), _bf(x3, "x3")
+    _, B, Cout, _ = dy2.shape
+    Cin = x3.shape[2] // 3
+    dw = torch.empty(Cout, Cin, 3, 3, device=dy2.device, dtype=torch.float32)
+    with _ConvBracket("wgrad_x3", 3, 1, Cin, Cout, H, W, B):
+        for j, (dpart, xoff) in enumerate(((0, 0), (1, 0), (0, Cin))):
+            L.check(lib().gd_conv3x3_wgrad(None, 0, dy2[dpart].data_ptr(), None, 0, x3.data_ptr() + 2 * xoff, 3 * Cin, None, None,
+                                           0, B, Cout, Cin, H, W, 1, int(j > 0), _ptr(dw), _stream()), "gd_conv3x3_wgrad")
     return dw
 
 
@@ -981,7 +1031,7 @@ def conv3x3_wgrad_nhwc(g: Tensor, x: Tensor, stride: int, want_bias: bool):
     dw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
     with _ConvBracket("wgrad_nhwc", 3, stride, Cin, Cout, g.shape[1], g.shape[2], B):
         L.check(lib().gd_conv3x3_wgrad(None, 0, _ptr(gt), None, 0, _ptr(x), Cin, None, None, 0, B, Cout, Cin, H, W, stride,
-                                       _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+                                       0, _ptr(dw), _stream()), "gd_conv3x3_wgrad")
     return dw, db
 
 

@@ -17,7 +17,7 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import kern as K
-from .config import config, sixteen_bit
+from .config import config, operand_mode, sixteen_bit
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY02, L.ACT_SIGMOID
 
@@ -25,6 +25,19 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY
 def _prec(layer: str = "other") -> int:
     """MFMA operand type of a layer class under the configured mode (config.sixteen_bit): 16-bit or exact f32"""
     return L.PREC_BF16 if sixteen_bit(layer) else L.PREC_FP32
+
+
+def _x3(layer: str) -> bool:
+    """split-bf16 route (config.operand_mode): the layer's products run as three bf16 MFMAs on hi / lo operand splits"""
+    return operand_mode(layer) == "x3"
+
+
+def _x3_eligible(x, w, stride, pad, act) -> bool:
+    """shapes the split-bf16 route serves (3x3 / stride 1 / pad 1 through the pixel-major kernels): Cin >= 32 keeps the
+    weight gradient's 32-channel chunk reads inside a [hi | lo | hi] row"""
+    return (x.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and act in (ACT_NONE, ACT_RELU)
+            and w.shape[1] >= 32 and w.shape[1] % 8 == 0 and w.shape[0] % 8 == 0 and (x.shape[2] * x.shape[3]) % 8 == 0
+            and x.shape[2] * x.shape[3] * 3 * max(w.shape[0], w.shape[1]) < (1 << 31))
 
 
 def _pam_f16() -> bool:
@@ -109,7 +122,19 @@ def _wide3x3(x, w, stride, pad, act, prec) -> bool:
 class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride: int, pad: int, act: int, prec=None, layer: str = "other"):
+        x3 = prec is None and _x3(layer) and _x3_eligible(x, w, stride, pad, act)
         prec = _prec(layer) if prec is None else prec
+        if x3:
+            # split-bf16: x -> [hi | lo | hi] pixel-major (3 Cin channels) against the weights [hi ; hi ; lo]; the same
+            # pack serves the weight gradient
+            B, Cin, H, W = x.shape
+            _, x16 = K.pack_split(x)
+            y = K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(K.split3_weights(_c(w), 1), 0), bias, w.shape[0], H, W,
+                                      relu=act == ACT_RELU)
+            ctx.save_for_backward(x16, w, y if act != ACT_NONE else None)
+            ctx.cfg = (stride, pad, act, prec, bias is not None)
+            ctx.wide = (H, W, True)
+            return y
         if _wide3x3(x, w, stride, pad, act, prec):
             # one pixel-major bf16 copy of x serves the forward (16-byte patch staging, no gather / convert in the
             # kernel) and the weight gradient; only that copy is kept for the backward
@@ -118,7 +143,7 @@ class Conv2dFn(Function):
             y = K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(_c(w), 0), bias, w.shape[0], H, W, relu=act == ACT_RELU)
             ctx.save_for_backward(x16, w, y if act != ACT_NONE else None)
             ctx.cfg = (stride, pad, act, prec, bias is not None)
-            ctx.wide = (H, W)
+            ctx.wide = (H, W, False)
             return y
         y = K.conv2d_fwd(x, w, bias, stride, pad, prec, act=act)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -134,8 +159,19 @@ class Conv2dFn(Function):
         if act != ACT_NONE:
             dy = K.act_bwd(y, dy, act)
         dx = dw = db = None
+        if ctx.wide is not None and ctx.wide[2]:
+            H, W, _ = ctx.wide
+            B, Cout = dy.shape[0], dy.shape[1]
+            dy2, dyt = K.pack_split(dy.view(B, Cout, H * W), want_plain=ctx.needs_input_grad[1], want_tr=ctx.needs_input_grad[0])
+            if ctx.needs_input_grad[0]:
+                dx = K.conv3x3_nhwc_f32out(dyt, K.conv3x3_nhwc_pack(K.split3_weights(_c(w), 0), 1), None, w.shape[1], H, W)
+            if ctx.needs_input_grad[1]:
+                dw = K.conv3x3_wgrad_x3(dy2, x, H, W)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = K.channel_sum(dy)
+            return dx, dw, db, None, None, None, None, None
         if ctx.wide is not None:
-            H, W = ctx.wide
+            H, W, _ = ctx.wide
             B, Cout = dy.shape[0], dy.shape[1]
             # dY once in both 16-bit layouts: channel-major for the weight gradient, pixel-major for the data gradient
             dy16, dyt16 = K.pack_bf16(dy.view(B, Cout, H * W), Cout, H * W, plain_shape=(Cout, H * W), t_shape=(H * W, Cout))
@@ -262,15 +298,23 @@ class DenseBlockFn(Function):
         # 16-bit mode: every layer's conv input max(0, bn(x)) is packed ONCE as a pixel-major bf16 copy; the forward conv
         # (NHWC kernel, fp32 result straight into the slab), and in the backward the weight gradient, read that copy
         # instead of gathering / normalising the fp32 NCHW slab in their staging loops
-        nhwc = (DENSE_NHWC and prec == L.PREC_BF16 and (H * W) % 8 == 0 and g % 8 == 0
-                and all((C0 + l * g) % 8 == 0 for l in range(nl)) and tuple(params[4].shape[2:]) == (3, 3))
+        aligned = ((H * W) % 8 == 0 and g % 8 == 0 and all((C0 + l * g) % 8 == 0 for l in range(nl))
+                   and tuple(params[4].shape[2:]) == (3, 3))
+        nhwc = DENSE_NHWC and prec == L.PREC_BF16 and aligned
+        # "mixed": the same route on split-bf16 operands -- max(0, bn(x)) packed once as [hi | lo | hi] pixel-major
+        x3 = prec == L.PREC_FP32 and _x3("dense3x3") and aligned and C0 >= 32 and H * W * 3 * (C0 + nl * g) < (1 << 31)
         packs: List[torch.Tensor] = []
         for l in range(nl):
             bw, bb, rm, rv, cw, cb = params[6 * l: 6 * l + 6]
             cl = C0 + l * g
             xin = slab[:, :cl]
             scale, shift, mean, invstd = _bn_prepare(xin, bw, bb, rm, rv, training, momentum, eps)
-            if nhwc:
+            if x3:
+                _, x16 = K.pack_split(xin, scale=scale, shift=shift, relu=True)
+                K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(K.split3_weights(_c(cw), 1), 0), cb, g, H, W,
+                                      out=slab[:, cl:cl + g])
+                packs.append(x16)
+            elif nhwc:
                 x16 = K.pack_nhwc16_affine(xin, scale, shift, True)
                 K.conv3x3_nhwc_f32out(x16, K.conv3x3_nhwc_pack(_c(cw), 0), cb, g, H, W, out=slab[:, cl:cl + g])
                 packs.append(x16)
@@ -279,13 +323,13 @@ class DenseBlockFn(Function):
                              out=slab[:, cl:cl + g])
             saved += [scale, shift, mean, invstd, cw]
         ctx.save_for_backward(slab, *saved, *packs)
-        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]], nhwc)
+        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]], nhwc, x3)
         return slab
 
     @staticmethod
     def backward(ctx, dslab_in):
         slab, *saved = ctx.saved_tensors
-        nl, C0, g, training, prec, has_bias, nhwc = ctx.cfg
+        nl, C0, g, training, prec, has_bias, nhwc, x3 = ctx.cfg
         packs = saved[5 * nl:]
         B, _, H, W = slab.shape
         dslab = torch.empty(slab.shape, device=slab.device, dtype=torch.float32)  # accumulated into below
@@ -296,7 +340,11 @@ class DenseBlockFn(Function):
             cl = C0 + l * g
             xin = slab[:, :cl]
             dy = dslab[:, cl:cl + g]
-            if nhwc:
+            if x3:
+                dy2, dyt = K.pack_split(_as3(dy), want_plain=True)
+                grads[6 * l + 4] = K.conv3x3_wgrad_x3(dy2, packs[l], H, W)
+                dxt = K.conv3x3_nhwc_f32out(dyt, K.conv3x3_nhwc_pack(K.split3_weights(_c(cw), 0), 1), None, cl, H, W)
+            elif nhwc:
                 dy16, dyt16 = K.pack_bf16(_as3(dy), g, H * W, plain_shape=(g, H * W), t_shape=(H * W, g))
                 grads[6 * l + 4] = K.conv3x3_wgrad_packed(dy16, packs[l], H, W)
                 dxt = K.conv3x3_nhwc_f32out(dyt16, K.conv3x3_nhwc_pack(_c(cw), 1), None, cl, H, W)

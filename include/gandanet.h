@@ -95,10 +95,12 @@ int gd_conv3x3(const gd_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
  * instead of dy -- worth it when Cin spans several 32-channel chunks, each of which re-reads every dY tile.
  * x_nhwc16 (may be NULL; needs in_scale == NULL): a dense PIXEL-MAJOR bf16 copy (B, H, W, x_ld) of x (the transposed
  * output of gd_pack_bf16, x_ld = Cin rounded up to 8); the patch staging is then 16-byte copies instead of strided
- * 4-byte gathers + converts -- worth it for wide convs (the 2C -> C fuse convs of DANetAttention). */
+ * 4-byte gathers + converts -- worth it for wide convs (the 2C -> C fuse convs of DANetAttention).  x_ld may exceed Cin: the
+ * rows of a wider pixel-major tensor (the split-bf16 pack's [hi | lo | hi] channels) are then read from a column offset.
+ * accumulate != 0: dw is added to instead of overwritten (the three launches of a split-bf16 weight gradient). */
 int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs, const void* x_nhwc16,
                      int x_ld, const float* in_scale, const float* in_shift, int in_relu, int B, int Cout, int Cin, int H,
-                     int W, int stride, float* dw, void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
+                     int W, int stride, int accumulate, float* dw, void* stream);   /* H, W = INPUT size; stride 1 or 2 (pad 1) */
 
 /* ------------------------------------------------------------------------------------------
  * "NT" GEMM with the long reduction split over workgroups:
@@ -391,6 +393,23 @@ int gd_chan_maxmean_bwd(const float* dy, const int* idx, float* dx, int B, int C
 /* d_raw[b][i] = sum_c a[b][c][i]*o[b][c][i] (per-pixel channel dot), delta = (*gamma) * d_raw */
 int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int C, int N, const float* gamma,
                 float* d_raw, float* delta, void* stream);
+/* split-bf16 ("x3") operands of set_precision("mixed"): every conv operand v = hi + lo (hi = bf16(v), lo = bf16(v - hi)),
+ * every product hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation (~2^-16 relative, 5x the rate of the
+ * exact f32 MFMA).  The split rides in the operand layout, so the 16-bit conv kernels above serve unchanged:
+ *   gd_pack_16_split  : fp32 (B, R, Cc) planes (optionally max(0, row_scale * x + row_shift) first: the BatchNorm + ReLU
+ *                       prologue of a dense layer, generator.py:36) -> up to three bf16 copies of the tile per output, copy j
+ *                       at `cs` elements behind copy j - 1, holding the lo part when bit j of `pattern` is set, else the hi
+ *                       part.  plain = (R, Cc) rows (channel-major, ldp == Cc), tr = the transpose (pixel-major rows of ldt
+ *                       elements): [hi | lo | hi] as 3 R channels (cs = R, ldt = 3 R, pattern 0b010) is the forward /
+ *                       data-gradient operand; separate hi / lo images (pattern 0b10) feed gd_conv3x3_wgrad's three
+ *                       accumulating launches.  R % 8 == 0, Cc % 8 == 0.
+ *   gd_split3_weights : w (A, Bn, Cn) fp32 -> (A, 3 Bn, Cn) fp32 [hi ; hi ; lo] along the middle axis (nn.Conv2d weights,
+ *                       generator.py:34,148,218,222 and the VGG stack of losses.py:41: Bn = Cin for the forward, A = 1 and
+ *                       Bn = Cout for the data gradient); gd_conv3x3_nhwc_pack then makes the 16-bit operator. */
+int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift, int relu,
+                     void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr, long t_bs, int ldt,
+                     long t_cs, int t_ncopy, int t_pattern, void* stream);
+int gd_split3_weights(const float* w, long A, long Bn, long Cn, float* out, void* stream);
 /* fp16 operand mode of gd_pam_flash_bwd (autograd of generator.py:115-122 under set_precision("fp16" | "mixed")): IEEE
  * fp16 loses everything below 6e-8, and gamma * dOut of a real training step sits below that.  All outputs of the backward
  * are linear in dOut, so it is packed as scales[0] * dOut with scales[0] = gamma * 2^k chosen so that the largest element has

@@ -705,3 +705,78 @@ def test_rccl_comm_c_abi_single_rank(gd):
     finally:
         L.check(lib.gd_comm_destroy(), "gd_comm_destroy")
     assert lib.gd_comm_world() == 0
+
+
+# ---- split-bf16 ("x3") operands of set_precision("mixed") -------------------------------------------------------------
+def test_split_pack_layouts_and_weight_split(gd):
+    """gd_pack_16_split / gd_split3_weights against their definition: hi = bf16(v), lo = bf16(v - hi); pixel-major
+    [hi | lo | hi] (3 C channels per pixel) and channel-major hi / lo images; optional BatchNorm-affine + ReLU first;
+    the input may be a channel slice of a wider slab.  hi + lo reproduces v to 2^-16."""
+    _, K = _ops()
+    B, Ctot, C, H, W = 2, 96, 72, 8, 12
+    slab = seeded((B, Ctot, H, W), 51).to(DEV)
+    x = slab[:, :C]
+    sc, sh = seeded((C,), 52).to(DEV), seeded((C,), 53, 0.3).to(DEV)
+    for affine in (False, True):
+        ref = x.cpu()
+        if affine:
+            ref = torch.relu(ref * sc.cpu().view(1, C, 1, 1) + sh.cpu().view(1, C, 1, 1))
+        hi = bf16_round(ref)
+        lo = bf16_round(ref - hi)
+        plain, tr = K.pack_split(x, scale=sc if affine else None, shift=sh if affine else None, relu=affine, want_plain=True)
+        assert plain.shape == (2, B, C, H * W) and tr.shape == (B, H * W, 3 * C)
+        tol = 0.0 if not affine else 1e-6          # fmaf in the kernel vs mul + add here: a last-bit matter before rounding
+        for got, want, nm in ((plain[0].float().cpu(), hi.view(B, C, -1), "plain hi"), (plain[1].float().cpu(), lo.view(B, C, -1), "plain lo"),
+                              (tr[..., :C].float().cpu(), hi.view(B, C, -1).transpose(1, 2), "tr hi"),
+                              (tr[..., C:2 * C].float().cpu(), lo.view(B, C, -1).transpose(1, 2), "tr lo"),
+                              (tr[..., 2 * C:].float().cpu(), hi.view(B, C, -1).transpose(1, 2), "tr hi (second copy)")):
+            if affine:     # a value that lands on a rounding boundary may fall either way: compare hi + lo instead of bits
+                continue
+            assert torch.equal(got, want), nm
+        rec = (plain[0].float() + plain[1].float()).cpu().view(B, C, H, W)
+        assert ((rec - ref).abs() <= 2.0 ** -16 * ref.abs() + 1e-30 + tol).all()
+        rec_t = (tr[..., :C].float() + tr[..., C:2 * C].float()).cpu().transpose(1, 2).reshape(B, C, H, W)
+        assert torch.equal(rec_t, rec)
+    w = seeded((24, 40, 3, 3), 54, 0.2).to(DEV)
+    whi = bf16_round(w.cpu())
+    w1 = K.split3_weights(w, 1).cpu()
+    assert torch.equal(w1[:, :40], whi) and torch.equal(w1[:, 40:80], whi) and torch.equal(w1[:, 80:], w.cpu() - whi)
+    w0 = K.split3_weights(w, 0).cpu()
+    assert torch.equal(w0[:24], whi) and torch.equal(w0[24:48], whi) and torch.equal(w0[48:], w.cpu() - whi)
+
+
+@pytest.mark.parametrize("case", [(2, 136, 16, 24, 24, True, False), (1, 368, 16, 16, 184, False, True),
+                                  (2, 64, 24, 8, 64, True, True), (1, 32, 8, 8, 8, False, False)])
+def test_conv3x3_split_bf16_vs_fp64(gd, case):
+    """the split-bf16 route of a 3x3 / stride 1 / pad 1 conv (forward, data gradient, weight gradient in three
+    accumulating launches, bias gradient) against torch in fp64: three bf16 MFMAs per product reach ~2^-16, two orders
+    of magnitude under plain bf16 operands (2e-3) -- asserted at 1e-4 (max-norm, relative to the output scale).
+    Cin = 136 is not a multiple of the weight gradient's 32-channel chunk: its last chunk reads into the lo columns of
+    the [hi | lo | hi] row, and those output rows must be dropped."""
+    ops, _ = _ops()
+    B, Cin, H, W, Cout, bias, relu = case
+    x = seeded((B, Cin, H, W), 61)
+    w = seeded((Cout, Cin, 3, 3), 62, 1.0 / math.sqrt(Cin * 9))
+    b = seeded((Cout,), 63, 0.1) if bias else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1)
+    if relu:
+        yr = torch.relu(yr)
+    go = seeded(tuple(yr.shape), 64)
+    yr.backward(go.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if bias else None
+    with gd.precision("fp32"), gd.layer_override(other="x3"):
+        y = ops.conv2d(xd, wd, bd, 1, 1, ops.ACT_RELU if relu else ops.ACT_NONE)
+        y.backward(go.to(DEV))
+    assert_close(y, yr.float(), 1e-4, "y")
+    assert_close(xd.grad, xr.grad.float(), 1e-4, "dx")
+    assert_close(wd.grad, wr.grad.float(), 1e-4, "dw")
+    if bias:
+        assert_close(bd.grad, br.grad.float(), 1e-5, "db")
+    # and it is NOT the exact route by accident: plain bf16 operands on the same inputs are ~100x further away
+    xb = x.to(DEV).requires_grad_(True)
+    with gd.precision("bf16"):
+        yb = ops.conv2d(xb, w.to(DEV), None if b is None else b.to(DEV), 1, 1, ops.ACT_RELU if relu else ops.ACT_NONE)
+    assert relmax(yb, yr.float()) > 20 * relmax(y, yr.float())

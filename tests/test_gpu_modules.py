@@ -247,6 +247,23 @@ def test_denseblock_vs_reference_fixture(gd, golden_dir):
     assert int(m.layers[0].bn.num_batches_tracked) == 1
 
 
+def test_denseblock_mixed_split_bf16_vs_reference_fixture(gd, golden_dir):
+    """DenseBlock(4, 64, 24) fixture under "mixed": every layer's max(0, bn(x)) packed as [hi | lo | hi], forward / data
+    gradient / weight gradient on split-bf16 operands -- at fp32-mode tolerances x10 (measured ~1e-5)"""
+    from gan_danet_amd.generator import DenseBlock
+    fx = load_golden(golden_dir, "denseblock_64_8x8")
+    m = DenseBlock(4, 64, 24)
+    fill_module(m)
+    m.to(DEV).train()
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with gd.precision("mixed"):
+        y = m(x)
+        y.backward(fx["go"].to(DEV))
+    assert_close(y, fx["y"], 1e-4, "y")
+    assert_close(x.grad, fx["gx"], 2e-3, "dx", rell2)
+    _check_param_grads(m, fx, 2e-3, rell2)
+
+
 def test_denseblock_bf16_pixel_major_packs_vs_reference_fixture(gd, golden_dir):
     """16-bit mode: every dense layer's conv input max(0, bn(x)) is packed once as a pixel-major bf16 copy
     (gd_pack_16_affine) that feeds the NHWC forward kernel and the weight gradient; the data gradient runs on the packed dY.
