@@ -749,7 +749,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
 //   dY tile is staged once for 32 NW input channels, no wave multiplies an all-zero m-tile, and the workgroup has
 //   NW x 64 threads to keep loads in flight (with waves = m-tiles a Cout of 24 left 128 threads per workgroup).
 template <int NW, int S, bool CS, bool PIPED = false>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NW * 64, (CS && PIPED) ? 1 : 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int BM = CS ? 32 : 32 * NW, NT = 64 * NW, NCH = CS ? NW : 1;
     constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
     __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
@@ -987,6 +987,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_wgrad_kernel(const WgradAr
 
 }  // namespace
 
+static const bool g_wgrad_cs_piped = getenv("GD_WGRAD_CS_PIPED") ? atoi(getenv("GD_WGRAD_CS_PIPED")) != 0 : true;   // A/B switch
+
 // dw (Cout, Cin, 3, 3) fp32 is overwritten (accumulate = 0) or added to.  Same input-transform contract as gd_conv2d.
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
                                 const void* x_nhwc16, int x_ld, const float* in_scale, const float* in_shift, int in_relu,
@@ -1034,7 +1036,11 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16
     a.tiles_per_split = (int)((ntiles + splits - 1) / splits);
     splits = (ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     dim3 grid(groups, mblocks, (unsigned)splits);
-    if (cs) {
+    if (cs && a.dy16 && a.x16 && g_wgrad_cs_piped) {
+        // both operands 16-bit (the dense layers' packs): the same software pipeline as the wide convs below
+        if (cs_nw == 3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<3, 1, true, true>), grid, dim3(192), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, true, true>), grid, dim3(256), 0, s, a);
+    } else if (cs) {
         if (cs_nw == 3) hipLaunchKernelGGL((conv3x3_wgrad_kernel<3, 1, true>), grid, dim3(192), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, true>), grid, dim3(256), 0, s, a);
     } else if (stride == 1 && a.dy16 && a.x16 && best_nw >= 4) {
