@@ -304,7 +304,7 @@ def main():
     # measured by tools/run_profiles.sh at the commit named in the file, at exactly config 3's launch shape
     roof = None
     traffic, traffic_commit = {}, None
-    tpath = os.path.join(ROOT, "profiles", "r02_pam_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pam_traffic.json")
     if os.path.exists(tpath) and cfg in (3, 4) and B == 32 and T == 256:
         with open(tpath) as f:
             tj = json.load(f)

@@ -103,6 +103,8 @@ SIGNATURES = {
     "gd_adamw": (_i, [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f, _p]),
     "gd_pam_flash_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _p, _p]),
     "gd_pam_key_sqnorm_max": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "gd_pam_fwd_shift_ws_bytes": (_sz, [_i, _i]),
+    "gd_pam_flash_fwd_shift": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p, _l, _p, _p, _i, _p, _sz, _p]),
     "gd_pam_flash_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _l, _p, _sz, _p]),
     "gd_pam_bwd_scratch_bytes": (_sz, [_i, _i]),
     "gd_pam_k64_variant": (None, [_i, _i]),

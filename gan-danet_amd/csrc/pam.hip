@@ -60,7 +60,10 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
                                                             const float* __restrict__ gamma, const float* __restrict__ x,
                                                             long x_bs, float* __restrict__ out, long out_bs,
                                                             float* __restrict__ o_attn, float* __restrict__ lse,
-                                                            const float* __restrict__ k_sqmax) {
+                                                            const float* __restrict__ k_sqmax,
+                                                            const float* __restrict__ mshift, int* __restrict__ redo) {
+    // redo != NULL without mshift: the fallback pass of the sampled-shift sweep -- only workgroups flagged there run
+    if (redo && !mshift && redo[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
     constexpr int CP = CT * 32;
     constexpr int NSUB = KT / 32;                   // 32-key sub-tiles per staged tile
     constexpr int VROWCH = KT / 8 + 1;              // 16-byte chunks per V row (data + 1 pad)
@@ -248,8 +251,18 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     // inside the exponent range of the P operand type for every query of the wave, the whole sweep runs with m = 0:
     // no row maximum, no cross-half shuffle, no test, no rescale branch (8 % of the kernel at the bench shape).
     // k_sqmax[b] = max_j |k_j|^2 comes from gd_pam_key_sqnorm_max; NULL keeps the running maximum unconditionally.
+    // Sampled shift (gd_pam_row_shift): ANY per-query shift m_i gives the same softmax as long as exp2(s - m_i) stays in
+    // range; m_i = the maximum of the query's logits over a strided sample of the keys is at most the true row maximum
+    // (so the row sum is >= ~1: no underflow) and, for every distribution short of a > 100-unit gap between the sample
+    // and the true maximum, close enough that fp32 / bf16 exponents hold the rest.  The sweep then runs max-free
+    // whatever the logits' magnitude; a row sum outside (1e-30, 1e30) flags the workgroup for the fallback pass.
     bool nomax = false;
-    if (k_sqmax) {
+    if (mshift) {
+        float mv = mshift[(long)b * Npad + q0 + r];                    // bf16-representable by construction
+        m = mv;
+        if (h) qf[1][7] = (short)(__builtin_bit_cast(unsigned int, -mv) >> 16);   // d = 31 lives in lane half 1
+        nomax = true;
+    } else if (k_sqmax) {
         float q2 = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -268,6 +281,10 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     else sweep(std::false_type{});
 
     if (ONES) l = __shfl(o[CT - 1][15], r + 32, 64);   // channel Cp-1 = accumulator row 31: register 15 of lane half 1
+    if (mshift) {
+        const bool bad = !(l > 1e-30f && l < 1e30f) && (q0 + r) < N;       // NaN / inf / 0: the shift missed this row
+        if (__syncthreads_or(bad) && tid == 0) redo[blockIdx.y * gridDim.x + blockIdx.x] = 1;
+    }
     const int qi = q0 + r;
     if (qi < N) {
         const float inv_l = 1.f / l;
@@ -287,6 +304,59 @@ __global__ __launch_bounds__(NW * 64, 2) void pam_fwd_dma_kernel(const unsigned 
     }
 }
 
+
+// m[b][i] = max over NS strided sample keys j < N of q_i . k_j (log2 domain: q is pre-scaled), rounded UP to bf16.
+// Thread = query; the sample keys sit in LDS (NS x 32 16-bit).  q slot 31 is zero in memory (the kernels only use it in
+// registers), so k's ones column does not enter.  Padded queries (zero rows) get 0.
+template <int NS, bool F16>
+__global__ __launch_bounds__(256) void pam_row_shift_kernel(const unsigned short* __restrict__ qt,
+                                                           const unsigned short* __restrict__ kt, int N, int Npad,
+                                                           float* __restrict__ mshift) {
+    __shared__ __attribute__((aligned(16))) unsigned short ks[NS * 32];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long nb = (long)b * Npad;
+    const int stride = N / NS > 0 ? N / NS : 1;
+    for (int c = tid; c < NS * 4; c += 256) {
+        const int j = c >> 2, part = c & 3;
+        const long key = (long)j * stride < N ? (long)j * stride : (long)N - 1;
+        *reinterpret_cast<u32x4_t*>(ks + j * 32 + part * 8) = *reinterpret_cast<const u32x4_t*>(kt + (nb + key) * 32 + part * 8);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= Npad) return;
+    float q[32];
+    {
+        const u32x4_t* qp = reinterpret_cast<const u32x4_t*>(qt + (nb + i) * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4_t w = qp[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q[c * 8 + 2 * e] = pam::unpack_lo<F16>(w[e]);
+                q[c * 8 + 2 * e + 1] = pam::unpack_hi<F16>(w[e]);
+            }
+        }
+        q[31] = 0.f;
+    }
+    float best = -3.0e38f;
+    for (int j = 0; j < NS; ++j) {
+        const u32x4_t* kp = reinterpret_cast<const u32x4_t*>(ks + j * 32);      // same address in every lane: LDS broadcast
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4_t w = kp[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d = fmaf(q[c * 8 + 2 * e], pam::unpack_lo<F16>(w[e]), d);
+                d = fmaf(q[c * 8 + 2 * e + 1], pam::unpack_hi<F16>(w[e]), d);
+            }
+        }
+        best = fmaxf(best, d);
+    }
+    const unsigned int wb = __builtin_bit_cast(unsigned int, best);
+    const float up = __builtin_bit_cast(float, best > 0.f ? (wb + 0xFFFFu) & 0xFFFF0000u : wb & 0xFFFF0000u);
+    mshift[nb + i] = up;
+}
 
 // =====================================================================================================
 // backward, part 1c: dK^T / dV^T, transpose-read variant.  Only Q [i][d] and dO [i][c] are staged per query
@@ -718,9 +788,49 @@ __global__ __launch_bounds__(256) void pam_key_sqnorm_max_kernel(const unsigned 
         default: gd_set_error("pam: Cp must be 32..192"); return -1; \
     }
 
+static int pam_fwd_launch(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
+                          int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out,
+                          long out_bs, float* o_attn, float* lse, const float* k_sqnorm_max, const float* mshift, int* redo,
+                          void* stream);
+
 extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                                 int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out,
                                 long out_bs, float* o_attn, float* lse, const float* k_sqnorm_max, void* stream) {
+    return pam_fwd_launch(qt, kt, v, B, N, Npad, C, Cp, v_ones, f16, gamma, x, x_bs, out, out_bs, o_attn, lse, k_sqnorm_max,
+                          nullptr, nullptr, stream);
+}
+
+// The same forward with the max-free sweep for logits of ANY magnitude (bf16 operands): a prepass takes every query's
+// maximum over `nsample` (128 / 256 / 512) strided keys as its softmax shift (see pam_fwd_dma_kernel); workgroups whose row
+// sums leave the fp32-safe range are redone by the running-maximum sweep (second launch, everyone else exits at once).
+// ws: gd_pam_fwd_shift_ws_bytes(B, Npad) bytes.
+extern "C" size_t gd_pam_fwd_shift_ws_bytes(int B, int Npad) {
+    return (size_t)B * Npad * sizeof(float) + (size_t)B * (Npad / 256) * sizeof(int);
+}
+extern "C" int gd_pam_flash_fwd_shift(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
+                                      int v_ones, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
+                                      float* o_attn, float* lse, int nsample, void* ws, size_t ws_bytes, void* stream) {
+    GD_CHECK_ARG(qt && kt && ws && B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_fwd_shift: bad arguments");
+    GD_CHECK_ARG(ws_bytes >= gd_pam_fwd_shift_ws_bytes(B, Npad), "gd_pam_flash_fwd_shift: workspace too small");
+    GD_CHECK_ARG(nsample == 128 || nsample == 256 || nsample == 512, "gd_pam_flash_fwd_shift: nsample must be 128, 256 or 512");
+    hipStream_t s = (hipStream_t)stream;
+    float* mshift = reinterpret_cast<float*>(ws);
+    int* redo = reinterpret_cast<int*>(mshift + (size_t)B * Npad);
+    GD_CHECK_ARG(hipMemsetAsync(redo, 0, (size_t)B * (Npad / 256) * sizeof(int), s) == hipSuccess, "gd_pam_flash_fwd_shift: memset failed");
+    const dim3 g(Npad / 256, B);
+    const unsigned short *q16 = (const unsigned short*)qt, *k16 = (const unsigned short*)kt;
+    if (nsample == 128) hipLaunchKernelGGL((pam_row_shift_kernel<128, false>), g, dim3(256), 0, s, q16, k16, N, Npad, mshift);
+    else if (nsample == 256) hipLaunchKernelGGL((pam_row_shift_kernel<256, false>), g, dim3(256), 0, s, q16, k16, N, Npad, mshift);
+    else hipLaunchKernelGGL((pam_row_shift_kernel<512, false>), g, dim3(256), 0, s, q16, k16, N, Npad, mshift);
+    int rc = pam_fwd_launch(qt, kt, v, B, N, Npad, C, Cp, v_ones, 0, gamma, x, x_bs, out, out_bs, o_attn, lse, nullptr, mshift, redo, stream);
+    if (rc) return rc;
+    return pam_fwd_launch(qt, kt, v, B, N, Npad, C, Cp, v_ones, 0, gamma, x, x_bs, out, out_bs, o_attn, lse, nullptr, nullptr, redo, stream);
+}
+
+static int pam_fwd_launch(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
+                          int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out,
+                          long out_bs, float* o_attn, float* lse, const float* k_sqnorm_max, const float* mshift, int* redo,
+                          void* stream) {
     GD_CHECK_ARG(qt && kt && v && gamma && x && out && o_attn && lse, "gd_pam_flash_fwd: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && Npad >= N && Npad % 256 == 0, "gd_pam_flash_fwd: Npad must be a multiple of 256 >= N");
     GD_CHECK_ARG(C > 0 && Cp >= C && Cp % 32 == 0 && Cp <= 192, "gd_pam_flash_fwd: Cp must be a multiple of 32, C <= Cp <= 192");
@@ -732,7 +842,7 @@ extern "C" int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, i
     // reads of THIS kernel (experiment, wrong numerics) changed nothing: it is not LDS-bandwidth bound.
     const dim3 grid(Npad / 256, B), block(512);
     hipStream_t s = (hipStream_t)stream;
-#define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse, k_sqnorm_max
+#define PAM_FWD_ARGS (const unsigned short*)qt, (const unsigned short*)kt, (const unsigned short*)v, N, Npad, C, gamma, x, x_bs, out, out_bs, o_attn, lse, k_sqnorm_max, mshift, redo
     if (f16) {
         if (v_ones) {
             PAM_DISPATCH_CT(Cp / 32, hipLaunchKernelGGL((pam_fwd_dma_kernel<CT, 8, 128, true, true>), grid, block, 0, s, PAM_FWD_ARGS));

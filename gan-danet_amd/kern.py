@@ -772,6 +772,26 @@ def pam_flash_fwd(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_a
                                        _ptr(k_sqmax), _stream()), "gd_pam_flash_fwd")
 
 
+PAM_SHIFT = os.environ.get("GD_PAM_SHIFT", "0") != "0"       # bf16 forward: sampled per-query shift + max-free sweep (opt-in: see DESIGN 5.2)
+PAM_SHIFT_SAMPLES = int(os.environ.get("GD_PAM_SHIFT_SAMPLES", "256"))
+
+
+def pam_flash_fwd_shift(qt, kt, v, B, N, Npad, Cn, Cp, gamma, x, out, o_attn, lse, r_alg: int = 32, v_ones: bool = False,
+                        nsample: Optional[int] = None, return_flags: bool = False):
+    """gd_pam_flash_fwd_shift: bf16 forward with the sampled-shift max-free sweep + fallback pass for flagged workgroups"""
+    _bf(qt, "qt"), _bf(kt, "kt")
+    nbytes = int(lib().gd_pam_fwd_shift_ws_bytes(B, Npad))
+    ws = torch.empty(nbytes // 4, device=qt.device, dtype=torch.int32)
+    with _Bracket("pam_flash_fwd", 2.0 * N * N * (r_alg + Cn) * B):
+        L.check(lib().gd_pam_flash_fwd_shift(_ptr(qt), _ptr(kt), _ptr(v), B, N, Npad, Cn, Cp, int(v_ones), _ptr(gamma), _ptr(x),
+                                             _bview(x), _ptr(out), _bview(out), _ptr(o_attn), _ptr(lse),
+                                             int(nsample or PAM_SHIFT_SAMPLES), _ptr(ws), nbytes, _stream()),
+                "gd_pam_flash_fwd_shift")
+    if return_flags:
+        return ws[B * Npad:].clone()           # 1 = the workgroup (256 queries) was redone with the running maximum
+    return None
+
+
 # backward form (gandanet.h GD_PAM_BWD_*): GD_PAM_BWD=0 K64 + fp32 atomics for dQ (default), 1 K64 + bf16 parts
 # (bitwise reproducible), 2 the round-1 K32 kernel with bf16 parts, 3 two kernels without scratch.
 # set_deterministic(True) moves the default from 0 to 1.

@@ -408,9 +408,13 @@ def _pam_forward(x, wq, bq, wk, bk, wv, bv, gamma_p, out3, prec):
         y3 = None
         o_attn = torch.empty(B, Cn, N, device=x.device, dtype=torch.float32)
         lse = torch.empty(B, N, device=x.device, dtype=torch.float32)
-        k_sqmax = K.pam_key_sqnorm_max(kt, N, f16) if K.PAM_NOMAX else None
-        K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0, f16=f16,
-                        k_sqmax=k_sqmax)
+        if K.PAM_SHIFT and not f16:
+            # bf16 operands: per-query softmax shift from a strided key sample, max-free sweep for logits of any magnitude
+            K.pam_flash_fwd_shift(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0)
+        else:
+            k_sqmax = K.pam_key_sqnorm_max(kt, N, f16) if K.PAM_NOMAX else None
+            K.pam_flash_fwd(qt, kt, vn, B, N, Np, Cn, Cp, gamma_p, x3, out3, o_attn, lse, r_alg=r, v_ones=ones >= 0, f16=f16,
+                            k_sqmax=k_sqmax)
         return True, (qt, kt, kn, vt, o_attn, lse)
     prec = prec if sixteen_bit("pam") else L.PREC_FP32     # the reference-shaped product chain below
     qt_, kt_ = K.transpose(q), K.transpose(k)              # (B, N, r)

@@ -327,6 +327,16 @@ int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum
 int gd_pam_flash_fwd(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp,
                      int v_ones, int f16, const float* gamma, const float* x, long x_bs, float* out, long out_bs,
                      float* o_attn, float* lse, const float* k_sqnorm_max, void* stream);
+/* gd_pam_flash_fwd (generator.py:115-122) with the max-free sweep for logits of ANY magnitude, bf16 operands: softmax is
+ * invariant under a per-query shift, so a prepass takes m_i = max over `nsample` (128 | 256 | 512) strided keys of q_i . k_j
+ * -- at most the true row maximum, hence row sums >= ~1 -- and the sweep runs exp2(s - m_i) without row maximum, test or
+ * rescale.  Workgroups whose row sums leave (1e-30, 1e30) (the sample missed the true maximum by > ~100 log2 units) are
+ * flagged and redone by the running-maximum sweep in a second launch in which every other workgroup exits at once.
+ * ws: gd_pam_fwd_shift_ws_bytes(B, Npad) bytes of scratch.  Same outputs as gd_pam_flash_fwd. */
+size_t gd_pam_fwd_shift_ws_bytes(int B, int Npad);
+int gd_pam_flash_fwd_shift(const void* qt, const void* kt, const void* v, int B, int N, int Npad, int C, int Cp, int v_ones,
+                           const float* gamma, const float* x, long x_bs, float* out, long out_bs, float* o_attn, float* lse,
+                           int nsample, void* ws, size_t ws_bytes, void* stream);
 /* k_sqnorm_max (B floats, or NULL): max_j |k_j|^2 of each image's packed keys.  Softmax is shift-invariant; when
  * |q_i| * max_j |k_j| (in log2 units, q is pre-scaled) stays inside the exponent range of the P operand type for every
  * query of a wave, that wave sweeps the keys without a running maximum (no per-tile max / test / rescale).  NULL: the

@@ -138,6 +138,50 @@ def test_pam_online_softmax_rescale_branch(gd, c):
     assert_close(y, yo, 3e-2, "spiked key")
 
 
+@pytest.mark.parametrize("spike", [False, True])
+def test_pam_forward_sampled_shift_and_its_fallback(gd, spike):
+    """gd_pam_flash_fwd_shift (the bf16 forward of the timed mode since round 3): every query's softmax shift is its
+    maximum over a strided sample of the keys and the sweep keeps no running maximum, whatever the logits' magnitude
+    (here +-60 log2 units: four times what the norm bound of the plain max-free sweep allows).  Against an fp64 softmax on
+    the operand-rounded q, k, v, ragged N.
+    spike: one key that is NOT in the sample (stride 5: keys 0, 5, 10, ...) beats one query's sampled maximum by ~400
+    units -> exp2 overflows, the row sum is inf, the workgroup (and only it) is flagged and redone by the running-maximum
+    sweep: same answer, through the other code path (guide rule 26: a rare data-dependent branch needs an input that
+    forces it)."""
+    from gan_danet_amd import kern as K
+    B, C, r, N = 2, 56, 7, 700
+    Np, Cp = 768, 64
+    q, k = seeded((B, r, N), 321, 3.0), seeded((B, r, N), 322, 3.0)
+    if spike:
+        q[1, 0, :] = 0.0                # dimension 0 is silent for every query of image 1 but one ...
+        q[1, 0, 300] = 10.0
+        k[1, 0, 303] = 40.0             # ... whose logit against key 303 (not a multiple of 5) is 400 * log2(e) = 577 units
+    v, x = seeded((B, C, N), 323), seeded((B, C, N), 324)
+    gamma = torch.full((1,), 0.7, device=DEV)
+    qd, kd, vd, xd = (t.to(DEV) for t in (q, k, v, x))
+    _, qt = K.pack_bf16(qd, r, N, scale_imm=K.LOG2E, t_shape=(Np, 32))
+    _, kt = K.pack_bf16(kd, r, N, plain_shape=(32, Np), t_shape=(Np, 32), perm16=True, ones_row=31)
+    vn, _ = K.pack_bf16(vd, C, N, plain_shape=(Cp, Np), perm16=True, ones_row=Cp - 1)
+    out, o, lse = torch.empty_like(xd), torch.empty_like(xd), torch.empty(B, N, device=DEV)
+    flags = K.pam_flash_fwd_shift(qt, kt, vn, B, N, Np, C, Cp, gamma, xd, out, o, lse, r_alg=r, v_ones=True, nsample=128,
+                                  return_flags=True)
+    e = torch.einsum("bdi,bdj->bij", bf16_round(q * K.LOG2E).double() / K.LOG2E, bf16_round(k).double())
+    oref = torch.einsum("bcj,bij->bci", bf16_round(v).double(), torch.softmax(e, dim=2))
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert_close(o, oref, 1e-2, "O")
+    assert_close(lse, torch.logsumexp(e, dim=2), 1e-2, "lse")
+    assert_close(out, 0.7 * oref + x.double(), 1e-2, "out")
+    want = torch.zeros(B, Np // 256, dtype=torch.int32)
+    if spike:
+        want[1, 300 // 256] = 1
+    assert torch.equal(flags.cpu().view(B, -1), want), f"redo flags {flags.cpu().view(B, -1).tolist()}"
+    # the running-maximum kernel on the same operands agrees (different rounding points of P: not bitwise)
+    out2, o2, lse2 = torch.empty_like(xd), torch.empty_like(xd), torch.empty(B, N, device=DEV)
+    K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, xd, out2, o2, lse2, r_alg=r, v_ones=True)
+    assert_close(o, o2.cpu(), 1e-2, "O vs running maximum")
+    assert_close(lse, lse2.cpu(), 1e-4, "lse vs running maximum")
+
+
 @pytest.mark.parametrize("f16", [False, True])
 def test_pam_forward_max_free_choice_is_workgroup_uniform(gd, f16):
     """the max-free / running-maximum choice must be made per WORKGROUP (each instantiation owns a
