@@ -9,7 +9,7 @@ The directory is called ``gan-danet_amd`` (repo contract); import it as ``gan_da
 repo-root ``gan_danet_amd.py`` registers the package under that name -- or through the reference's own
 import paths ``from models import ...`` / ``from model import ...``.
 """
-from .config import config, layer_override, precision, set_precision
+from .config import config, layer_override, precision, set_precision, set_sync_bn
 from .kern import set_deterministic
 from .discriminator import SRGAND, Discriminator1
 from .generator import (CAMModule, CBAMBlock, DANetAttention, DenseBlock, DenseLayer, FlexibleUpsamplingModule,

@@ -72,6 +72,9 @@ SIGNATURES = {
     "gd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
     "gd_affine_act": (_i, [_p, _l, _p, _p, _i, _i, _l, _i, _p, _l, _p]),
     "gd_bn_act_bwd": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p, _p, _p, _l, _i, _p, _p]),
+    "gd_bn_stats_local": (_i, [_p, _l, _i, _i, _l, _p, _p, _p]),
+    "gd_bn_stats_merge": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
+    "gd_bn_act_bwd_dx": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _f, _i, _i, _l, _i, _p, _l, _i, _p]),
     "gd_bicubic_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
     "gd_bicubic_bwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
     "gd_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),

@@ -27,6 +27,10 @@ class _Config:
     precision: str = "bf16"
     # per-layer-class override {class: "exact" | "x3" | "16"} on top of ``precision`` (attribution runs only)
     override: Dict[str, str] = field(default_factory=dict)
+    # BatchNorm statistics under data parallelism: False = per-replica batch statistics (PyTorch-DDP semantics, what
+    # BASELINE config 4 implies); True = SyncBN -- the statistics (forward) and the dy sums (backward) of every
+    # training-mode BatchNorm2d are reduced over all ranks, so world = W on B/W samples each equals one device on B samples
+    sync_bn: bool = False
 
 
 config = _Config()
@@ -60,6 +64,10 @@ def precision(p: str):
         yield
     finally:
         config.precision = old
+
+
+def set_sync_bn(on: bool) -> None:
+    config.sync_bn = bool(on)
 
 
 @contextmanager

@@ -40,17 +40,24 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int parts, float eps,
-                                                         float momentum, float* __restrict__ mean,
-                                                         float* __restrict__ invstd, float* running_mean,
-                                                         float* running_var) {
+// Chan merge (fp64) of `parts` (count, mean, M2) records of a channel; record i of channel c sits at
+// ws[(c * c_stride + i * p_stride) * 3] (the kernel's own partials: c_stride = parts, p_stride = 1; the all-gathered
+// per-rank records of SyncBN, (world, C, 3): c_stride = 1, p_stride = C).  stats_out != NULL: the merged record is
+// written there instead of mean / invstd (the local half of SyncBN).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int parts, long c_stride,
+                                                         long p_stride, float eps, float momentum,
+                                                         float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* running_mean, float* running_var,
+                                                         float* __restrict__ stats_out) {
     __shared__ double redd[4];
     const int c = blockIdx.x;
-    const float* w = ws + (long)c * parts * 3;
+    const float* w0 = ws + (long)c * c_stride * 3;
+    const long ps = p_stride * 3;
     double n = 0, sm = 0;
     for (int i = threadIdx.x; i < parts; i += 256) {
-        n += w[i * 3];
-        sm += (double)w[i * 3] * w[i * 3 + 1];
+        const float* w = w0 + i * ps;
+        n += w[0];
+        sm += (double)w[0] * w[1];
     }
     auto bsum = [&](double v) {
         v = gd_wave_sum_d(v);
@@ -64,11 +71,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const double mu = sm / n;
     double m2 = 0;
     for (int i = threadIdx.x; i < parts; i += 256) {
-        const double dm = (double)w[i * 3 + 1] - mu;
-        m2 += (double)w[i * 3 + 2] + (double)w[i * 3] * dm * dm;
+        const float* w = w0 + i * ps;
+        const double dm = (double)w[1] - mu;
+        m2 += (double)w[2] + (double)w[0] * dm * dm;
     }
     m2 = bsum(m2);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && stats_out) {
+        stats_out[c * 3 + 0] = (float)n;
+        stats_out[c * 3 + 1] = (float)mu;
+        stats_out[c * 3 + 2] = (float)m2;
+    } else if (threadIdx.x == 0) {
         const double var = m2 / n;
         mean[c] = (float)mu;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -258,8 +270,35 @@ extern "C" int gd_bn_stats(const float* x, long x_bs, int B, int C, long HW, flo
     GD_CHECK_ARG((long)B * cpi <= 65535, "gd_bn_stats: too many parts");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(C, B * cpi), dim3(256), 0, s, x, x_bs, C, HW, cpi, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, B * cpi, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, B * cpi, (long)B * cpi, 1L, eps, momentum, mean, invstd,
+                       running_mean, running_var, (float*)nullptr);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- SyncBN (optional flag; default is per-replica statistics) -------------------------------------------
+// forward : every rank reduces its shard to one (count, mean, M2) record per channel (gd_bn_stats_local), the records are
+//           all-gathered (2 x 3 C floats per rank: torch.distributed) and merged by the same Chan formula
+//           (gd_bn_stats_merge) -> the statistics of the GLOBAL batch on every rank, running statistics included.
+// backward: the per-channel sums of dy and dy * xhat (gd_bn_act_bwd with dx = NULL) are all-reduced, then
+//           gd_bn_act_bwd_dx forms dx from the global sums and the global element count.
+extern "C" int gd_bn_stats_local(const float* x, long x_bs, int B, int C, long HW, float* stats, float* ws, void* stream) {
+    GD_CHECK_ARG(x && stats && ws && B > 0 && C > 0 && HW > 0, "gd_bn_stats_local: bad arguments");
+    const int cpi = chunks_per_image(HW);
+    GD_CHECK_ARG((long)B * cpi <= 65535, "gd_bn_stats_local: too many parts");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(C, B * cpi), dim3(256), 0, s, x, x_bs, C, HW, cpi, ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, B * cpi, (long)B * cpi, 1L, 0.f, 0.f, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, stats);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gd_bn_stats_merge(const float* stats_all, int world, int C, float eps, float momentum, float* mean,
+                                 float* invstd, float* running_mean, float* running_var, void* stream) {
+    GD_CHECK_ARG(stats_all && mean && invstd && world > 0 && C > 0, "gd_bn_stats_merge: bad arguments");
+    GD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "gd_bn_stats_merge: running stats must come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats_all, world, 1L, (long)C, eps,
+                       momentum, mean, invstd, running_mean, running_var, (float*)nullptr);
     GD_LAUNCH_CHECK();
     return 0;
 }
@@ -302,6 +341,22 @@ extern "C" int gd_affine_act(const float* x, long x_bs, const float* scale, cons
     GD_CHECK_ARG((long)B * cpi <= 65535, "gd_affine_act: too many parts");
     hipLaunchKernelGGL(affine_act_kernel, dim3(C, B * cpi), dim3(256), 0, (hipStream_t)stream, x, x_bs, scale, shift, HW,
                        cpi, act, y, y_bs);
+    GD_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx (+)= scale * (g - dbeta_sum * inv_n - xhat * dgamma_sum * inv_n) from EXTERNALLY reduced sums (SyncBN: the all-reduced
+// dbeta / dgamma of every rank, inv_n = 1 / the global element count per channel)
+extern "C" int gd_bn_act_bwd_dx(const float* dy, long dy_bs, const float* x, long x_bs, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* dgamma_sum, const float* dbeta_sum,
+                                float inv_n, int B, int C, long HW, int act, float* dx, long dx_bs, int accumulate_dx,
+                                void* stream) {
+    GD_CHECK_ARG(dy && x && scale && shift && mean && invstd && dgamma_sum && dbeta_sum && dx, "gd_bn_act_bwd_dx: null pointer");
+    GD_CHECK_ARG(B > 0 && C > 0 && HW > 0 && inv_n > 0.f, "gd_bn_act_bwd_dx: bad sizes");
+    const int cpi = chunks_per_image(HW);
+    GD_CHECK_ARG((long)B * cpi <= 65535, "gd_bn_act_bwd_dx: too many parts");
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(C, B * cpi), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs, scale, shift, mean,
+                       invstd, dgamma_sum, dbeta_sum, inv_n, HW, cpi, act, 1, dx, dx_bs, accumulate_dx);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -290,6 +290,44 @@ def bn_stats(x: Tensor, eps: float, momentum: float, running_mean: Optional[Tens
     return mean, invstd
 
 
+def bn_stats_local(x: Tensor) -> Tensor:
+    """SyncBN, local half: (C, 3) = (count, mean, M2) of this rank's shard per channel (gd_bn_stats_local)"""
+    bs = _bview(x, "bn input")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    stats = torch.empty(Cn, 3, device=x.device, dtype=torch.float32)
+    L.check(lib().gd_bn_stats_local(_ptr(x), bs, B, Cn, HW, _ptr(stats), _ptr(bn_ws(B, Cn, HW, x.device)), _stream()),
+            "gd_bn_stats_local")
+    return stats
+
+
+def bn_stats_merge(stats_all: Tensor, eps: float, momentum: float, running_mean: Optional[Tensor],
+                   running_var: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """SyncBN: (world, C, 3) all-gathered records -> mean, invstd of the global batch (+ running statistics)"""
+    _dense(stats_all, "gathered BN records")
+    world, Cn, _ = stats_all.shape
+    mean = torch.empty(Cn, device=stats_all.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    L.check(lib().gd_bn_stats_merge(_ptr(stats_all), world, Cn, eps, momentum, _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                                    _ptr(running_var), _stream()), "gd_bn_stats_merge")
+    return mean, invstd
+
+
+def bn_act_bwd_dx(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, dgamma_sum: Tensor,
+                  dbeta_sum: Tensor, inv_n: float, act: int, dx: Optional[Tensor] = None, accumulate_dx: bool = False) -> Tensor:
+    """SyncBN: dx from the all-reduced per-channel sums (gd_bn_act_bwd_dx)"""
+    dbs, xbs = _bview(dy, "bn dy"), _bview(x, "bn x")
+    B, Cn = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if dx is None:
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        accumulate_dx = False
+    L.check(lib().gd_bn_act_bwd_dx(_ptr(dy), dbs, _ptr(x), xbs, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                                   _ptr(dgamma_sum), _ptr(dbeta_sum), float(inv_n), B, Cn, HW, act, _ptr(dx), _bview(dx),
+                                   int(accumulate_dx), _stream()), "gd_bn_act_bwd_dx")
+    return dx
+
+
 def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, invstd: Tensor) -> Tuple[Tensor, Tensor]:
     scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
     L.check(lib().gd_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), gamma.numel(), _ptr(scale),
@@ -317,12 +355,17 @@ def affine_act(x: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], act:
 
 
 def bn_act_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, mean: Tensor, invstd: Tensor, act: int,
-               train: bool, dx: Optional[Tensor] = None, accumulate_dx: bool = False, want_dx: bool = True):
+               train: bool, dx: Optional[Tensor] = None, accumulate_dx: bool = False, want_dx: bool = True,
+               sums_out: Optional[Tensor] = None):
+    """``sums_out`` (2, C): dgamma / dbeta are written into its rows (SyncBN all-reduces that one buffer)"""
     dbs, xbs = _bview(dy, "bn dy"), _bview(x, "bn x")
     B, Cn = x.shape[0], x.shape[1]
     HW = x[0, 0].numel()
-    dgamma = torch.empty(Cn, device=x.device, dtype=torch.float32)
-    dbeta = torch.empty_like(dgamma)
+    if sums_out is not None:
+        dgamma, dbeta = _dense(sums_out)[0], sums_out[1]
+    else:
+        dgamma = torch.empty(Cn, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty_like(dgamma)
     if want_dx and dx is None:
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     L.check(lib().gd_bn_act_bwd(_ptr(dy), dbs, _ptr(x), xbs, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), None,

@@ -220,9 +220,32 @@ def activation(x, act: int):
 # =====================================================================================================
 # BatchNorm2d (+ activation)               generator.py:32,61,149,189,219,223
 # =====================================================================================================
+def _sync_bn_active() -> bool:
+    """SyncBN (config.sync_bn) applies when there is more than one rank to synchronise with"""
+    if not config.sync_bn:
+        return False
+    from .parallel import is_distributed
+    return is_distributed()
+
+
+def _all_gather_records(stats: torch.Tensor) -> torch.Tensor:
+    """(C, 3) per-rank BatchNorm records -> (world, C, 3) on every rank (torch.distributed: plumbing)"""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(stats.shape), device=stats.device, dtype=stats.dtype)
+    if dist.get_backend() == "gloo":
+        dist.all_gather([out[r] for r in range(world)], stats)
+    else:
+        dist.all_gather_into_tensor(out, stats)
+    return out
+
+
 def _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps):
     """statistics (+ running update) and the folded affine; returns (scale, shift, mean, invstd)"""
-    if training:
+    if training and _sync_bn_active():
+        mean, invstd = K.bn_stats_merge(_all_gather_records(K.bn_stats_local(x)), eps, momentum, rmean, rvar)
+        scale, shift = K.bn_fold(gamma, beta, mean, invstd)
+    elif training:
         mean, invstd = K.bn_stats(x, eps, momentum, rmean, rvar)
         scale, shift = K.bn_fold(gamma, beta, mean, invstd)
     else:
@@ -231,20 +254,39 @@ def _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps):
     return scale, shift, mean, invstd
 
 
+def _bn_bwd(dy, x, scale, shift, mean, invstd, act, training, sync, dx=None, accumulate_dx=False):
+    """backward of act(bn(x)): (dgamma, dbeta, dx).  sync (SyncBN, training): this rank's dgamma / dbeta are the parameter
+    gradients (the gradient all-reduce sums them over ranks like every other parameter); dx uses their all-reduced sums and
+    the global element count"""
+    if not (sync and training):
+        return K.bn_act_bwd(dy, x, scale, shift, mean, invstd, act, training, dx=dx, accumulate_dx=accumulate_dx)
+    import torch.distributed as dist
+    Cn = x.shape[1]
+    sums = torch.empty(2, Cn, device=x.device, dtype=torch.float32)
+    K.bn_act_bwd(dy, x, scale, shift, mean, invstd, act, training, want_dx=False, sums_out=sums)
+    local = torch.empty_like(sums)
+    K.copy_slab(sums.view(1, 2 * Cn, 1), local.view(1, 2 * Cn, 1))
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    n_global = x.shape[0] * x[0, 0].numel() * dist.get_world_size()
+    dx = K.bn_act_bwd_dx(dy, x, scale, shift, mean, invstd, sums[0], sums[1], 1.0 / n_global, act, dx=dx,
+                         accumulate_dx=accumulate_dx)
+    return local[0], local[1], dx
+
+
 class BnActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, training: bool, momentum: float, eps: float, act: int):
         scale, shift, mean, invstd = _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps)
         y = K.affine_act(x, scale, shift, act)
         ctx.save_for_backward(x, scale, shift, mean, invstd)
-        ctx.cfg = (act, training)
+        ctx.cfg = (act, training, training and _sync_bn_active())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean, invstd = ctx.saved_tensors
-        act, training = ctx.cfg
-        dgamma, dbeta, dx = K.bn_act_bwd(_c(dy), x, scale, shift, mean, invstd, act, training)
+        act, training, sync = ctx.cfg
+        dgamma, dbeta, dx = _bn_bwd(_c(dy), x, scale, shift, mean, invstd, act, training, sync)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -262,18 +304,18 @@ class BnReluConvFn(Function):
         scale, shift, mean, invstd = _bn_prepare(x, gamma, beta, rmean, rvar, training, momentum, eps)
         y = K.conv2d_fwd(x, w, bias, 1, pad, prec, in_scale=scale, in_shift=shift, in_relu=True)
         ctx.save_for_backward(x, scale, shift, mean, invstd, w)
-        ctx.cfg = (training, prec, pad, bias is not None)
+        ctx.cfg = (training, prec, pad, bias is not None, training and _sync_bn_active())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean, invstd, w = ctx.saved_tensors
-        training, prec, pad, has_bias = ctx.cfg
+        training, prec, pad, has_bias, sync = ctx.cfg
         dy = _c(dy)
         dw = K.conv2d_wgrad(dy, x, w.shape[2], 1, pad, prec, in_scale=scale, in_shift=shift, in_relu=True)
         db = K.channel_sum(dy) if has_bias else None
         dxt = K.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), 1, pad, prec)
-        dgamma, dbeta, dx = K.bn_act_bwd(dxt, x, scale, shift, mean, invstd, ACT_RELU, training)
+        dgamma, dbeta, dx = _bn_bwd(dxt, x, scale, shift, mean, invstd, ACT_RELU, training, sync)
         return dx, dgamma, dbeta, None, None, dw, db, None, None, None, None
 
 
@@ -323,13 +365,13 @@ class DenseBlockFn(Function):
                              out=slab[:, cl:cl + g])
             saved += [scale, shift, mean, invstd, cw]
         ctx.save_for_backward(slab, *saved, *packs)
-        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]], nhwc, x3)
+        ctx.cfg = (nl, C0, g, training, prec, [p is not None for p in params[5::6]], nhwc, x3, training and _sync_bn_active())
         return slab
 
     @staticmethod
     def backward(ctx, dslab_in):
         slab, *saved = ctx.saved_tensors
-        nl, C0, g, training, prec, has_bias, nhwc, x3 = ctx.cfg
+        nl, C0, g, training, prec, has_bias, nhwc, x3, sync = ctx.cfg
         packs = saved[5 * nl:]
         B, _, H, W = slab.shape
         dslab = torch.empty(slab.shape, device=slab.device, dtype=torch.float32)  # accumulated into below
@@ -353,8 +395,8 @@ class DenseBlockFn(Function):
                 dxt = K.conv2d_dgrad(dy, cw, (H, W), 1, 1, prec)
             if has_bias[l]:
                 grads[6 * l + 5] = K.channel_sum(dy)
-            dgamma, dbeta, _ = K.bn_act_bwd(dxt, xin, scale, shift, mean, invstd, ACT_RELU, training,
-                                            dx=dslab[:, :cl], accumulate_dx=True)
+            dgamma, dbeta, _ = _bn_bwd(dxt, xin, scale, shift, mean, invstd, ACT_RELU, training, sync,
+                                       dx=dslab[:, :cl], accumulate_dx=True)
             grads[6 * l + 0], grads[6 * l + 1] = dgamma, dbeta
         dx = torch.empty(B, C0, H, W, device=slab.device, dtype=torch.float32)
         K.copy_slab(dslab[:, :C0], dx)

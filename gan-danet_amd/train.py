@@ -44,8 +44,13 @@ class GanTrainer:
                  compute_ssim: bool = True, tv_global_batch_semantics: bool = False,
                  batch_real_fake: bool = True, input_attention: Optional[nn.Module] = None,
                  reduce_gradients: bool = True, external_world: Optional[int] = None,
-                 shard_bytes: int = 256 << 20) -> None:
+                 shard_bytes: int = 256 << 20, sync_bn: Optional[bool] = None) -> None:
         self.G, self.D, self.perceptual = G, D, perceptual
+        # sync_bn: BatchNorm statistics reduced over all ranks (config.sync_bn; process-wide).  With
+        # tv_global_batch_semantics=True a world of W ranks on B/W samples each then takes the step one device takes on B
+        if sync_bn is not None:
+            from .config import set_sync_bn
+            set_sync_bn(sync_bn)
         # optional gate on the combined input (the notebook's attention_module / senet_module, L145-171,
         # L229-232: SqueezeExcitation or CBAMBlock); its parameters join the generator's optimiser (L165-175)
         self.input_attention = input_attention

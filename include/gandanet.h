@@ -146,6 +146,18 @@ int gd_bn_stats(const float* x, long x_bs, int B, int C, long HW, float eps, flo
 /* scale[c] = gamma[c]*invstd[c], shift[c] = beta[c] - mean[c]*scale[c]  (the folded affine) */
 int gd_bn_fold(const float* gamma, const float* beta, const float* mean, const float* invstd, int C,
                float* scale, float* shift, void* stream);
+/* SyncBN (optional; torch.nn.SyncBatchNorm semantics on the BatchNorm2d sites of generator.py:32,61,149,189,
+ * 219,223): gd_bn_stats_local reduces this rank's shard to stats (C, 3) = (count, mean, M2) per channel; the caller
+ * all-gathers the records of all ranks into stats_all (world, C, 3); gd_bn_stats_merge Chan-merges them (fp64) into the
+ * GLOBAL batch's mean / invstd (+ running statistics, unbiased variance of the global count).  Backward: gd_bn_act_bwd
+ * with dx = NULL gives this rank's dgamma / dbeta (they are also the parameter gradients); after their all-reduce (sum)
+ * gd_bn_act_bwd_dx forms dx with inv_n = 1 / (global batch * HW). */
+int gd_bn_stats_local(const float* x, long x_bs, int B, int C, long HW, float* stats, float* ws, void* stream);
+int gd_bn_stats_merge(const float* stats_all, int world, int C, float eps, float momentum, float* mean, float* invstd,
+                      float* running_mean, float* running_var, void* stream);
+int gd_bn_act_bwd_dx(const float* dy, long dy_bs, const float* x, long x_bs, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, const float* dgamma_sum, const float* dbeta_sum, float inv_n,
+                     int B, int C, long HW, int act, float* dx, long dx_bs, int accumulate_dx, void* stream);
 /* eval mode: invstd from running_var (also written to invstd_out when non-NULL) */
 int gd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                     float eps, int C, float* scale, float* shift, float* invstd_out, void* stream);

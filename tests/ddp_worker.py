@@ -43,7 +43,9 @@ with gd.precision(prec):
     broadcast_module(D)
     G.train(), D.train()
     shard_bytes = int(os.environ.get("DDP_SHARD_BYTES", "0"))
-    tr = gd.GanTrainer(G, D, perceptual=None, shard_bytes=shard_bytes)   # built AFTER init_process_group: world = 2
+    sync_bn = os.environ.get("DDP_SYNC_BN", "0") == "1"
+    tr = gd.GanTrainer(G, D, perceptual=None, shard_bytes=shard_bytes, sync_bn=sync_bn,
+                       tv_global_batch_semantics=sync_bn)   # built AFTER init_process_group: world = 2
     if shard_bytes:
         assert any(sp.p is D.fc1.weight for sp in tr.sharded), "fc1 should take the reduce-scatter / sharded-AdamW path"
     if backend == "nccl" and shard_bytes:

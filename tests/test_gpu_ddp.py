@@ -139,3 +139,44 @@ def test_rccl_backend_world1_sharded_path_equals_plain_step(tmp_path):
         for k in plain[net]:
             assert torch.equal(plain[net][k], rccl[net][k]), f"RCCL sharded path changed {net}.{k}"
     assert plain["loss_g"] == rccl["loss_g"] and plain["loss_d"] == rccl["loss_d"]
+
+
+def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(tmp_path):
+    """SyncBN flag (optional): two ranks on two samples each, BatchNorm statistics and dy sums reduced over
+    the ranks and the TV term scaled to the global batch, take the SAME G+D steps as one device on the four samples --
+    parameters, BN running statistics (identical on both ranks now) and the generator output.  Tolerance = the
+    emulation test's: AdamW's early steps are sign-like, so elements whose gradient sits at fp32 round-off level may
+    move by +-lr either way when the summation order changes."""
+    import gan_danet_amd as gd
+    steps = 2
+    r0, r1 = _run_two_ranks(str(tmp_path / "sync"), steps, DDP_DETERMINISTIC="1", DDP_SYNC_BN="1")
+    for net in ("G", "D"):
+        for k in r0[net]:
+            if not k.endswith("num_batches_tracked"):
+                assert torch.equal(r0[net][k], r1[net][k]), f"SyncBN replicas differ in {net}.{k}"
+    gb = 4
+    x, tgt = seeded((gb, 8, 16, 16), 21).to(DEV), seeded((gb, 1, 64, 64), 22).to(DEV)
+    gd.set_deterministic(True)
+    try:
+        with gd.precision("fp32"):
+            G = gd.FlexibleUpsamplingModule(input_channels=8).to(DEV)
+            D = gd.Discriminator1().to(DEV)
+            with torch.no_grad():
+                D(tgt[:1])
+            fill_module(G), fill_module(D)
+            G.train(), D.train()
+            tr = gd.GanTrainer(G, D, perceptual=None)
+            for _ in range(steps):
+                tr.step(x, tgt, 0.5)
+        torch.cuda.synchronize()
+    finally:
+        gd.set_deterministic(False)
+    for net, mod in (("G", G), ("D", D)):
+        for k, v in mod.state_dict().items():
+            if k.endswith("num_batches_tracked") or k.endswith("key.bias"):
+                continue
+            e = rell2(v, r0[net][k])
+            assert e <= 2e-3, f"{net}.{k}: SyncBN 2 x 2 samples vs one device on 4 samples: rel err {e:.2e}"
+    bn_keys = [k for k in r0["G"] if k.endswith("running_mean") or k.endswith("running_var")]
+    for k in bn_keys:        # (the second step's statistics see parameters that already differ by the AdamW sign-step noise above)
+        assert rell2(G.state_dict()[k], r0["G"][k]) <= 1e-3, f"running statistic {k}"
