@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     // values are requested without a wait (SMEM returns through lgkmcnt: the loop-top lgkmcnt(0) covers them) and summed
     // per wave into dbg[(image, key block, wave)][8] = {wait+barrier, head, S+dP, dS, dV^T, dK^T+dQ^T, -, tiles}
     constexpr bool STAMP = (ORDER & 64) != 0;
-    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned int sacc_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, stw = 0;     // stw: between the counted waits and the barrier
+    unsigned int sacc_t[6] = {0, 0, 0, 0, 0, 0}, sacc_w = 0;
     auto stamp = [&](auto ic) {
         if constexpr (STAMP) {
             unsigned long long& t = st[decltype(ic)::value];      // (a variable named only in an asm operand is not captured)
@@ -465,13 +465,15 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         else wait_vmcnt<PPW + 2 * AOPS>();
         if constexpr (STAMP) {
             // the previous iteration's stamps have landed behind this wait; st[0] = the end stamp of the iteration before it
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st[1]), "+s"(st[2]), "+s"(st[3]), "+s"(st[4]), "+s"(st[5]), "+s"(st[6]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st[1]), "+s"(st[2]), "+s"(st[3]), "+s"(st[4]), "+s"(st[5]), "+s"(st[6]), "+s"(stw) :: "memory");
             if (it > 1) {
                 sacc_t[0] += (unsigned int)(st[1] - st[0]);          // loop back + counted waits + barrier
+                sacc_w += (unsigned int)(stw - st[0]);               //   of which: loop back + the counted vmcnt / lgkmcnt waits
 #pragma unroll
                 for (int k = 1; k < 6; ++k) sacc_t[k] += (unsigned int)(st[k + 1] - st[k]);
             }
             st[0] = st[6];
+            asm volatile("s_memtime %0" : "=s"(stw));
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's exchange-buffer writes are in LDS
         }
@@ -667,7 +669,8 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             else if constexpr (id == CT) fb[id] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
             else fb[id] = tr_issue2<(id - CT - 1) * 32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
         };
-        if constexpr (PH2) issue(IC<0>{});             // dO^T of channel tile 0: in flight under the P hand-over below
+        constexpr bool HOIST = PH2 || (ORDER & 128) != 0;   // bit 7: only the hoisted first transpose reads of bit 5
+        if constexpr (HOIST) issue(IC<0>{});           // dO^T of channel tile 0: in flight under the dS arithmetic below
         bf16x8_t pf[2][2], dsf[2][2];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         auto step_id = [](int i) constexpr { return DQ_FIRST ? (i < 2 ? CT + 1 + i : i - 2) : i; };
         // transpose reads run LA steps ahead of their MFMAs (2 measured equal to 1: the waits are not what stalls)
         constexpr int LA = 1;
-        static_for<0, (LA < NSTEP ? LA : NSTEP)>([&](auto ic) { issue(IC<step_id(decltype(ic)::value)>{}); });
+        if constexpr (!HOIST) static_for<0, (LA < NSTEP ? LA : NSTEP)>([&](auto ic) { issue(IC<step_id(decltype(ic)::value)>{}); });
         static_for<0, NSTEP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int id = step_id(i);
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             unsigned int* o = dbg + (((long)b * gridDim.x + kb) * 4 + wave) * 8;
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = sacc_t[k];
-            o[6] = 0;
+            o[6] = sacc_w;
             o[7] = (unsigned int)(nqt - 2);
         }
     }
@@ -905,13 +908,15 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
         else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs, g_k64_dbg); \
         break;
         switch (g_k64_order == 1 ? 0 : g_k64_order == 2 ? 24 : g_k64_order == 3 ? 56 : g_k64_order == 4 ? 8
-                : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : -1) {
+                : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : g_k64_order == 7 ? 136 : g_k64_order == 8 ? 152 : -1) {
             K64_ORD(0)         // 1: the compiler-scheduled AGPR-form loop
             K64_ORD(8)         // 4: round-2 production (hand-placed dP phase)
             K64_ORD(24)        // 2: + unpacked dS multiplies
             K64_ORD(56)        // 3: + hand-placed second half
             K64_ORD(72)        // 5: production + segment stamps (diagnostic)
             K64_ORD(120)       // 6: hand-placed second half + segment stamps (diagnostic)
+            K64_ORD(136)       // 7: production + first transpose reads hoisted above the dS arithmetic
+            K64_ORD(152)       // 8: 7 + unpacked dS multiplies
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD

@@ -66,3 +66,5 @@ for variant in (5, 6):
         print(f"    {n:14s} {c:8.1f} cycles  ({100 * c / tot:5.1f} %)   MFMA cycles issued in it: {32 * m}")
     w = per.view(-1, 4, 6).mean(0)
     print("    by wave (wait+barrier): " + "  ".join(f"{w[i, 0].item():.0f}" for i in range(4)))
+    wq = (d[:, 6] / tiles).view(-1, 4).mean(0)
+    print("      of which loop back + counted vmcnt / lgkmcnt waits (before the barrier), by wave: " + "  ".join(f"{v.item():.0f}" for v in wq))
