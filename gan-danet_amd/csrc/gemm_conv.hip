@@ -249,7 +249,13 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 constexpr int XLD = BN + 32;   // elements per staged channel row
 
-template <int BM>
+// NS: 128-pixel sub-tiles per workgroup, the k loop OUTSIDE them: a workgroup then reads 512 NS contiguous bytes of every
+// channel row per k-tile instead of 512 (round 3 experiment on round 2's address-translation suspicion: the input is
+// fp32 NCHW, a k-tile touches 32 channel rows 4 HW bytes apart).  MEASURED at the bench shapes: NS = 2 / 4 are 20 - 50 %
+// SLOWER than NS = 1 (184 -> 230 projection: 3.1 / 3.6 / 3.6 ms; 184 -> 256 data gradient 1.7 / 2.2 / 3.0 ms): page
+// locality is not what holds this kernel back, occupancy (312 registers at NS = 4) costs more.  NS = 1 is the default;
+// the other instantiations stay behind GD_CONV1X1_NS for A/B runs.
+template <int BM, int NS>
 __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
     constexpr int LDA = BK + 8;
     constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
@@ -257,34 +263,34 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
     constexpr int TN = gd::TileGeom<BM>::TN;
     constexpr int KPT_A = BM / 8;
     __shared__ __attribute__((aligned(16))) unsigned short As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[BK * XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[NS * BK * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * (BN * NS);
     const int HW = d.Ho * d.Wo;
 
     const int am = tid % BM, akg = tid / BM;
     const bool a_row_ok = (m0 + am) < d.M;
     const float* a_row = d.a + (long)b * d.a_bs + (long)(m0 + am) * d.a_sm;
 
-    // X loader: thread -> (channel row xr = tid>>3 .. +0, pixel quad xq = tid&7 .. +8*i): 32 rows x 32 quads
-    const int xq = tid & 31, xr0 = tid >> 5;          // 8 threads rows apart: rows xr0 + 8*i, quad xq
+    // X loader: thread -> (channel rows xr0 + 8 i, pixel quad xq of every sub-tile): 32 rows x 32 quads x NS
+    const int xq = tid & 31, xr0 = tid >> 5;
     const float* x_img = d.x + (long)b * d.x_bs;
-    const int pq = n0 + xq * 4;                        // first pixel of this thread's quad
-    const bool q_full = pq + 3 < HW;
 
-    f32x16_t acc[TM][TN];
+    f32x16_t acc[NS][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int sb = 0; sb < NS; ++sb)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[sb][i][j][e] = 0.f;
 
     float ra[KPT_A];
-    float4 rx[4];
+    float4 rx[NS][4];
     const int T = (d.Ck + BK - 1) / BK;
     auto load_tile = [&](int t) {
         const int c0 = t * BK;
@@ -296,31 +302,37 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = c0 + xr0 + 8 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < d.Ck) {
-                const float* p = x_img + (long)c * HW + pq;
-                if (q_full) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (pq + 0 < HW) v.x = p[0];
-                    if (pq + 1 < HW) v.y = p[1];
-                    if (pq + 2 < HW) v.z = p[2];
-                }
-                if (d.in_scale) {
-                    const float sc = d.in_scale[c], sh = d.in_shift[c];
-                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-                    if (d.in_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            float sc = 1.f, sh = 0.f;
+            if (d.in_scale && c < d.Ck) { sc = d.in_scale[c]; sh = d.in_shift[c]; }
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                const int pq = n0 + sb * BN + xq * 4;              // first pixel of this thread's quad
+                const bool q_full = pq + 3 < HW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < d.Ck && pq < HW) {
+                    const float* p = x_img + (long)c * HW + pq;
+                    if (q_full) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (pq + 0 < HW) v.x = p[0];
+                        if (pq + 1 < HW) v.y = p[1];
+                        if (pq + 2 < HW) v.z = p[2];
                     }
-                    if (!q_full) {   // padding pixels stay zero
-                        if (pq + 0 >= HW) v.x = 0.f;
-                        if (pq + 1 >= HW) v.y = 0.f;
-                        if (pq + 2 >= HW) v.z = 0.f;
-                        v.w = 0.f;
+                    if (d.in_scale) {
+                        v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                        if (d.in_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        if (!q_full) {   // padding pixels stay zero
+                            if (pq + 0 >= HW) v.x = 0.f;
+                            if (pq + 1 >= HW) v.y = 0.f;
+                            if (pq + 2 >= HW) v.z = 0.f;
+                            v.w = 0.f;
+                        }
                     }
                 }
+                rx[sb][i] = v;
             }
-            rx[i] = v;
         }
     };
     auto store_tile = [&]() {
@@ -342,37 +354,43 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
             *reinterpret_cast<uint2*>(ap) = w;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint2 w;
-            w.x = gd_pack_bf2(rx[i].x, rx[i].y);
-            w.y = gd_pack_bf2(rx[i].z, rx[i].w);
-            *reinterpret_cast<uint2*>(Xs + (xr0 + 8 * i) * XLD + xq * 4) = w;
-        }
+        for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint2 w;
+                w.x = gd_pack_bf2(rx[sb][i].x, rx[sb][i].y);
+                w.y = gd_pack_bf2(rx[sb][i].z, rx[sb][i].w);
+                *reinterpret_cast<uint2*>(Xs + sb * (BK * XLD) + (xr0 + 8 * i) * XLD + xq * 4) = w;
+            }
     };
     // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
     auto compute_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t fa[TM], fb[TN];
+            bf16x8_t fa[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 fa[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const unsigned short* p = Xs + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
-                fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            for (int sb = 0; sb < NS; ++sb) {
+                bf16x8_t fb[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned short* p = Xs + sb * (BK * XLD) + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                    fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[sb][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
+                            acc[sb][i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
-                        acc[i][j], 0, 0, 0);
         }
     };
 
@@ -391,10 +409,12 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
 
     const float alpha = d.alpha ? *d.alpha : 1.f;
 #pragma unroll
+    for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int pn = n0 + wn * TN * 32 + j * 32 + r;
+            const int pn = n0 + sb * BN + wn * TN * 32 + j * 32 + r;
             if (pn >= HW) continue;
             // residual / accumulate operands: all loads before the first store (see conv3x3_halo_kernel's epilogue)
             float rsv[16], oldv[16];
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
                 if (m >= d.M) continue;
-                float v = acc[i][j][e] * alpha + rsv[e];
+                float v = acc[sb][i][j][e] * alpha + rsv[e];
                 if (d.bias) v += d.bias[m];
                 if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
@@ -471,10 +491,18 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
     static const int tr_env = getenv("GD_CONV1X1_TR") ? atoi(getenv("GD_CONV1X1_TR")) : 1;
     if (tr_env && conv1x1_tr_eligible(d)) {
         const int bm = d.M <= 32 ? 32 : (d.M <= 64 || (d.M % 128 != 0 && d.M % 128 <= 64)) ? 64 : 128;
-        dim3 grid(gd_cdiv((long)d.Ho * d.Wo, BN), gd_cdiv(d.M, bm), d.B);
-        if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_kernel<32>), grid, dim3(256), 0, s, d);
-        else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_kernel<64>), grid, dim3(256), 0, s, d);
-        else hipLaunchKernelGGL((conv1x1_tr_kernel<128>), grid, dim3(256), 0, s, d);
+        // long pixel runs per channel row (NS sub-tiles per workgroup) once the image is large enough to keep the chip full
+        static const int ns_env = getenv("GD_CONV1X1_NS") ? atoi(getenv("GD_CONV1X1_NS")) : 1;   // measured: NS 2 / 4 are 20-50 % SLOWER (round 3)
+        const long HWl = (long)d.Ho * d.Wo;
+        int ns = HWl * d.B >= (1L << 18) ? ns_env : 1;
+        if (bm == 128 && ns > 2) ns = 2;                  // 64 accumulator registers per sub-tile
+        if (ns != 1 && ns != 2 && ns != 4) ns = 1;
+        dim3 grid(gd_cdiv(HWl, BN * ns), gd_cdiv(d.M, bm), d.B);
+#define GD_C1X1(BM_, NS_) hipLaunchKernelGGL((conv1x1_tr_kernel<BM_, NS_>), grid, dim3(256), 0, s, d)
+        if (bm == 32) { if (ns == 4) GD_C1X1(32, 4); else if (ns == 2) GD_C1X1(32, 2); else GD_C1X1(32, 1); }
+        else if (bm == 64) { if (ns == 4) GD_C1X1(64, 4); else if (ns == 2) GD_C1X1(64, 2); else GD_C1X1(64, 1); }
+        else { if (ns == 2) GD_C1X1(128, 2); else GD_C1X1(128, 1); }
+#undef GD_C1X1
         GD_LAUNCH_CHECK();
         return 0;
     }
