@@ -348,8 +348,12 @@ def main():
             "data": "synthetic (randn tiles, random-init weights" + (", random-init VGG19 for the perceptual term)" if perc is not None else ")"),
             "config": {"workload": workload, "survey_config": cfg,
                        "per_gpu_batch": B, "global_batch": B * world, "tile": T, "parallelism": f"dp{world}",
-                       "storage": "fp32 activations/weights, 16-bit MFMA operands (" + args.precision + "), fp32 accumulate"
-                                  if args.precision != "fp32" else "fp32 everywhere (exact f32 MFMA)"},
+                       "storage": {"fp32": "fp32 everywhere (exact f32 MFMA)",
+                                   "mixed": "fp32 activations/weights; fused PAM on IEEE fp16 operands; 3x3 convs (generator, VGG) on "
+                                            "split-bf16 operands (hi*hi + lo*hi + hi*lo, ~2^-16); 1x1 convs / CAM / stem / "
+                                            "discriminator on the exact f32 MFMA; fp32 accumulate everywhere"}.get(
+                           args.precision, "fp32 activations/weights, 16-bit MFMA operands (" + args.precision +
+                           "; generator stem conv exact), fp32 accumulate")},
             **extra, "finite": finite,
             "g_out_rel_err": g_out_rel_err(gd, dev, args.precision),
             "roofline": roof,
