@@ -218,13 +218,21 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     constexpr int XW = 2 * 32 * XLD;               // per wave: the two key tiles' dS^T
     constexpr int QXLD = 36;                       // dQ exchange rows, floats
     constexpr int DLD = CP + 8;                    // V rows in LDS
+    // bit 8 (DQ16): dQ without the cross-wave exchange.  The dS^T images of all four waves are double-buffered; after the
+    // next iteration's barrier every wave forms ONE 16 x 16 sub-tile of the tile's dQ (queries 16 (wave & 1).., d columns
+    // 16 (wave >> 1)..) over ALL 256 keys of the workgroup with eight v_mfma_f32_16x16x32 (A = dS by transpose reads of the
+    // four images, B = the K rows of the 256 keys, held in registers) and adds it straight to dQ -- no fp32 exchange
+    // buffer, no 16 single-dword reads and 12 adds per tile, no LDS write in front of the barrier.
+    constexpr bool DQ16 = (ORDER & 256) != 0;
     constexpr int OFF_X = NSLOT * SLOT;
-    constexpr int OFF_XQ = OFF_X + 4 * XW;
+    constexpr int OFF_XQ = OFF_X + (DQ16 ? 2 : 1) * 4 * XW;
     constexpr int XQ_BUF = 4 * 32 * QXLD;          // floats per exchange buffer
-    constexpr int OFF_V = OFF_XQ + 2 * XQ_BUF * 2;
+    constexpr int OFF_V = OFF_XQ + (DQ16 ? 0 : 2 * XQ_BUF * 2);
     constexpr int VLDS = 2 - VREG;                 // key tiles per wave whose V rows live in LDS
     constexpr int V_ELEMS = 4 * VLDS * 32 * DLD;
-    constexpr int AOPS = ATOMIC ? 4 : 1;           // VMEM operations of one dQ hand-over per wave
+    constexpr int KLD = 264;                       // DQ16: K^T image rows [d][256 keys + 8 pad] (528 B: conflict-free 16-byte column reads)
+    constexpr int K_ELEMS = ((ORDER & 256) != 0) ? 32 * KLD : 0;
+    constexpr int AOPS = (ATOMIC || (ORDER & 256) != 0) ? 4 : 1;           // VMEM operations of one dQ hand-over per wave
     // schedule variants (A/B switches, see the loop): bit 0 DQ_FIRST, bit 1 HANDOVER_MID, bit 2 DMA_LATE
     constexpr bool DQ_FIRST = (ORDER & 1) != 0, HANDOVER_MID = (ORDER & 2) != 0, DMA_LATE = (ORDER & 4) != 0;
     constexpr bool VFORM = (ORDER & 8) != 0;        // S / dP / dQ-part tiles through VGPR-form asm MFMAs
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     // need P; the first transpose reads are requested before it
     constexpr bool PH2 = (ORDER & 32) != 0;
     static_assert(!PH2 || VFORM, "the hand-placed second half continues the hand-placed dP phase");
+    static_assert(!DQ16 || (VFORM && !PH2 && CT >= 4), "DQ16 rides in the hand-placed dP phase of the production schedule (>= 8 steps)");
     // bit 6 (diagnostic build only, tools/pam_stamps.py): s_memtime stamps at the segment seams of the tile loop; the
     // values are requested without a wait (SMEM returns through lgkmcnt: the loop-top lgkmcnt(0) covers them) and summed
     // per wave into dbg[(image, key block, wave)][8] = {wait+barrier, head, S+dP, dS, dV^T, dK^T+dQ^T, -, tiles}
@@ -251,8 +260,9 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     };
     static_assert(!HANDOVER_MID || DQ_FIRST, "the mid-iteration hand-over follows the early dQ steps");
     static_assert(DCH % 64 == 0 && (OFF_X % 8) == 0 && (OFF_XQ % 8) == 0 && (OFF_V % 8) == 0, "LDS carve");
-    static_assert((OFF_V + V_ELEMS) * 2 <= 163840, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned short lds[OFF_V + (V_ELEMS ? V_ELEMS : 8)];   // the ONLY LDS object
+    constexpr int OFF_K = OFF_V + (V_ELEMS ? V_ELEMS : 8);
+    static_assert((OFF_K + K_ELEMS) * 2 <= 163840, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned short lds[OFF_K + (K_ELEMS ? K_ELEMS : 8)];   // the ONLY LDS object
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,6 +283,16 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             // accumulator-row-ordered k-step)
             knA[k2][s] = *reinterpret_cast<const bf16x8_t*>(kn + ((long)b * 32 + r) * Npad + j0 + 32 * k2 + s * 16 + 8 * h);
         }
+    // DQ16: the K^T rows [d][key] of ALL 256 keys of the workgroup as an LDS image (kn is perm16 along the keys, which the
+    // A-side row addresses below follow): the B operand (k = key, n = d) of the dQ sub-tiles is read from it per tile
+    if constexpr (DQ16) {
+        unsigned short* Kimg = lds + OFF_K;
+        for (int c = tid; c < 32 * 32; c += 256) {
+            const int row = c >> 5, ch = c & 31;
+            *reinterpret_cast<u32x4_t*>(Kimg + row * KLD + ch * 8) =
+                *reinterpret_cast<const u32x4_t*>(kn + ((long)b * 32 + row) * Npad + (long)kb * 256 + ch * 8);
+        }
+    }
     bf16x8_t vB[VREG > 0 ? VREG : 1][2 * CT];
 #pragma unroll
     for (int k2 = 0; k2 < VREG; ++k2)
@@ -288,7 +308,10 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     }
     // dQ exchange buffers start at zero: iteration 0 hands over an all-zero "previous tile"
-    {
+    if constexpr (DQ16) {      // the dS^T images start at zero: iteration 0 forms the dQ of an all-zero "previous tile"
+        unsigned int* xz = reinterpret_cast<unsigned int*>(lds + OFF_X);
+        for (int c = tid; c < 2 * 4 * XW / 2; c += 256) xz[c] = 0u;
+    } else {
         float* xq = reinterpret_cast<float*>(lds + OFF_XQ);
         for (int c = tid; c < 2 * XQ_BUF; c += 256) xq[c] = 0.f;
     }
@@ -447,6 +470,57 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     };
 
+    // DQ16: the A fragments (dS[query][key], 16 queries x 32 keys per k-step) of the PREVIOUS tile by transpose reads of all
+    // four waves' dS^T images: lane group g = lane >> 4 takes the stored key positions 8g .. 8g+7 of a 32-key block, i.e. (kn
+    // is perm16) keys base_g + {0..3} and base_g + 8 + {0..3} with base_g = 4 (g & 1) + 16 (g >> 1): two reads per k-step;
+    // the B fragments (K[key][d]) are 16-byte reads of the K^T image.  Two batches of four k-steps (32 registers in flight).
+    struct Dq16Regs {
+        s16x4_t f[8];
+        bf16x8_t kb[4];
+    };
+    const unsigned int a_dq16 = lds_addr(lds + OFF_X + (4 * ((lane >> 4) & 1) + 16 * (lane >> 5) + (li >> 2)) * XLD + 16 * (wave & 1) + 4 * (li & 3));
+    const unsigned int a_k16 = lds_addr(lds + OFF_K + (16 * (wave >> 1) + (lane & 15)) * KLD + 8 * (lane >> 4));
+    auto dq16_issue = [&](Dq16Regs& dr, int buf, auto batch) {
+        constexpr int B0 = decltype(batch)::value * 4;
+        const unsigned int a = a_dq16 + (unsigned int)buf * (4 * XW * 2);
+        static_for<0, 4>([&](auto ic) {
+            constexpr int kp = B0 + decltype(ic)::value;
+            constexpr int off = ((kp >> 1) * XW + (kp & 1) * 32 * XLD) * 2;
+            dr.f[2 * (kp - B0)] = tr_issue<off>(a);
+            dr.f[2 * (kp - B0) + 1] = tr_issue<off + 8 * XLD * 2>(a);
+            dr.kb[kp - B0] = lds_issue128<kp * 64>(a_k16);
+        });
+    };
+    auto dq16_land = [&](Dq16Regs& dr) {          // a counted wait in front of this has covered the twelve reads
+        asm volatile("" : "+v"(dr.f[0]), "+v"(dr.f[1]), "+v"(dr.f[2]), "+v"(dr.f[3]), "+v"(dr.f[4]), "+v"(dr.f[5]), "+v"(dr.f[6]),
+                          "+v"(dr.f[7]), "+v"(dr.kb[0]), "+v"(dr.kb[1]), "+v"(dr.kb[2]), "+v"(dr.kb[3]));
+    };
+    auto dq16_mma = [&](Dq16Regs& dr, f32x4_t& acc, auto batch) {
+        static_for<0, 4>([&](auto ic) {
+            constexpr int kk = decltype(ic)::value;
+            const bf16x8_t a = tr_frag(dr.f[2 * kk], dr.f[2 * kk + 1]);
+            if constexpr (decltype(batch)::value == 0 && kk == 0) {
+                if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(dr.kb[kk]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(dr.kb[kk]));
+            } else {
+                if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(dr.kb[kk]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(dr.kb[kk]));
+            }
+        });
+    };
+    auto dq16_commit = [&](f32x4_t& acc, int tq) {      // rows = queries 16 (wave & 1) + 4 (lane >> 4) + e, columns = d
+        const int qrow = 16 * (wave & 1) + 4 * (lane >> 4), dcol = 16 * (wave >> 1) + (lane & 15);
+        if constexpr (ATOMIC) {
+            float* o = reinterpret_cast<float*>(dq_out) + (nb + (long)tq * 32 + qrow) * 32 + dcol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(o + e * 32, acc[e]);      // one wave-instruction = four 64-byte row segments
+        } else {
+            unsigned short* part = reinterpret_cast<unsigned short*>(dq_out) + (((long)b * (Npad / 256) + kb) * Npad + (long)tq * 32 + qrow) * 32 + dcol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e * 32] = (unsigned short)(pack2<false>(acc[e], 0.f) & 0xFFFFu);
+        }
+    };
+
     // the key-side operands above are complete: said with the BUILTIN so that the compiler's own wait-count pass knows it
     // (it cannot see a wait inside asm text and would otherwise put vmcnt(0) in front of their first use in the loop,
     // draining the DMA ring and the dQ atomics every tile)
@@ -497,6 +571,8 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         f32x4_t rc4[8];
         bf16x8_t qa0, qa1;
         HqRegs hq;
+        Dq16Regs dqr;
+        f32x4_t dq4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (VFORM) {
             const unsigned int a_rc = lds_addr(RC + 4 * h), a_qr = lds_addr(q_rows);
             rc4[0] = lds_issue128f<0>(a_rc);
@@ -569,12 +645,13 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 if constexpr (s == 0) {
                     // steps 0 and 1 go out together at s == 1 (mfma_v_first2x2); meanwhile, under the S MFMAs, the
                     // exchange-buffer reads of the hand-over (buffer written in iteration it-1) and fragment 2 are requested
-                    hq_issue(hq, (it + 1) & 1);
+                    if constexpr (DQ16) dq16_issue(dqr, (it + 1) & 1, IC<0>{});
+                    else hq_issue(hq, (it + 1) & 1);
                     if constexpr (DPD < 2 * CT) do_issue(IC<DPD>{});
                 } else if constexpr (s == 1) {
                     // fragments 0 and 1 landed: the reads behind them are fragment 2 (if any)
                     // (behind them: the hand-over reads and fragment 2 -- more than the counter can express: 15 is stricter)
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(dq_[0]), "+v"(dq_[1]) : "n"(ATOMIC ? 15 : (DPD < 2 * CT ? 5 : 4)) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(dq_[0]), "+v"(dq_[1]) : "n"(DQ16 ? 13 : ATOMIC ? 15 : (DPD < 2 * CT ? 5 : 4)) : "memory");     // DQ16: 12 batch reads + fragment 2 behind them
                     bf16x8_t v00, v10;
                     if (0 < VREG) v00 = vB[0][0];
                     else v00 = *reinterpret_cast<const bf16x8_t*>(v_rows + (0 - VREG) * 32 * DLD);
@@ -584,7 +661,8 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                     if constexpr (1 + DPD < 2 * CT) do_issue(IC<1 + DPD>{});     // into the ring slot of fragment 0
                 } else {
                     if constexpr (s + DPD < 2 * CT) do_issue(IC<s + DPD>{});
-                    constexpr int behind = (2 * CT - 1 - s) < DPD ? (2 * CT - 1 - s) : DPD;   // reads issued after fragment s
+                    // reads issued after fragment s (DQ16: batch 1's twelve reads sit behind fragments 3 and 4)
+                    constexpr int behind = (DQ16 && (s == 3 || s == 4)) ? 14 : ((2 * CT - 1 - s) < DPD ? (2 * CT - 1 - s) : DPD);
                     lds_wait128<behind>(dq_[s % (DPD + 1)]);
                     const bf16x8_t da = dq_[s % (DPD + 1)];
                     mfma_v_acc<F16>(dpacc[0], da, v_frag(0));
@@ -605,7 +683,11 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 // than fragment 2, whose wait has just passed (CT == 1 has no fragment 2: waited for here)
                 if constexpr (s == (2 * CT > 2 ? 2 : 1)) {
                     if constexpr (2 * CT <= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if constexpr (ATOMIC)
+                    if constexpr (DQ16) {
+                        dq16_land(dqr);
+                        dq16_mma(dqr, dq4, IC<0>{});                       // four 16-cycle MFMAs between dP steps
+                        dq16_issue(dqr, (it + 1) & 1, IC<1>{});            // batch 1 into the same registers
+                    } else if constexpr (ATOMIC)
                         asm volatile("" : "+v"(hq.v[0][0]), "+v"(hq.v[0][1]), "+v"(hq.v[0][2]), "+v"(hq.v[0][3]), "+v"(hq.v[1][0]),
                                           "+v"(hq.v[1][1]), "+v"(hq.v[1][2]), "+v"(hq.v[1][3]), "+v"(hq.v[2][0]), "+v"(hq.v[2][1]),
                                           "+v"(hq.v[2][2]), "+v"(hq.v[2][3]), "+v"(hq.v[3][0]), "+v"(hq.v[3][1]), "+v"(hq.v[3][2]),
@@ -613,7 +695,16 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                     else
                         asm volatile("" : "+v"(hq.q[0]), "+v"(hq.q[1]), "+v"(hq.q[2]), "+v"(hq.q[3]));
                 }
-                if constexpr (s == (2 * CT > 4 ? 4 : 2 * CT - 1)) hq_commit(hq, tprev);
+                if constexpr (DQ16 && s == 5) {             // fragment 5's wait (2 behind) has covered batch 1
+                    dq16_land(dqr);
+                    dq16_mma(dqr, dq4, IC<1>{});
+                }
+                if constexpr (DQ16 && s == 7) {
+                    // the sub-tile is final two dP steps (>= 64 cycles) behind its last MFMA; the tie keeps the adds here
+                    asm volatile("" : "+v"(dq4), "+v"(dpacc[0]));
+                    dq16_commit(dq4, tprev);
+                }
+                if constexpr (!DQ16 && s == (2 * CT > 4 ? 4 : 2 * CT - 1)) hq_commit(hq, tprev);
             });
             static_for<(2 * CT - 1 < 8 ? 2 * CT - 1 : 8), 8>(p_chunk);      // narrow C: the chunks no step was left for
             // the wait states between the last dP MFMA and the first VALU read of dP; PH2 reads it two MFMAs later
@@ -687,6 +778,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         // dS = P (dP - delta), its 16-bit pack and the dS^T image X[key][query] (this lane's 16 queries are 4 runs of 4),
         // four accumulator registers at a time: chunk c = key tile c >> 2, registers 4 (c & 3) ..
         u32x4_t dsw[2][2];
+        unsigned short* x_wr_it = x_wr + (DQ16 ? (it & 1) * (4 * XW) : 0);       // DQ16: this tile's image of the double buffer
         auto ds_chunk = [&](auto cc) {
             constexpr int c = decltype(cc)::value, k2 = c >> 2, q = c & 3;
 #pragma unroll
@@ -704,8 +796,8 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
             if constexpr ((q & 1) == 1) {              // k-step q >> 1 of key tile k2 is complete
                 const u32x4_t w = dsw[k2][q >> 1];
                 const u32x2_t lo = {w.x, w.y}, hi = {w.z, w.w};
-                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * (q >> 1)) = lo;
-                *reinterpret_cast<u32x2_t*>(x_wr + k2 * 32 * XLD + 16 * (q >> 1) + 8) = hi;
+                *reinterpret_cast<u32x2_t*>(x_wr_it + k2 * 32 * XLD + 16 * (q >> 1)) = lo;
+                *reinterpret_cast<u32x2_t*>(x_wr_it + k2 * 32 * XLD + 16 * (q >> 1) + 8) = hi;
                 dsf[k2][q >> 1] = __builtin_bit_cast(bf16x8_t, w);
             }
         };
@@ -741,7 +833,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 *reinterpret_cast<f32x4_t*>(xw + 8 * g) = v;
             }
         };
-        constexpr int NSTEP = CT + 3;
+        constexpr int NSTEP = DQ16 ? CT + 1 : CT + 3;       // DQ16: the dQ^T steps live in the NEXT iteration's dP phase
         if constexpr (PH2) {
             // dV^T steps as asm MFMA pairs in source order = schedule; the eight dS chunks are spread over the gaps
             // behind the pairs of the first steps (NCH per step, half behind each pair)
@@ -807,7 +899,22 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    dq_handover((nqt + 1) & 1, tprev);
+    if constexpr (DQ16) {
+        Dq16Regs dqr;
+        f32x4_t dq4;
+        dq16_issue(dqr, (nqt + 1) & 1, IC<0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dq16_land(dqr);
+        dq16_mma(dqr, dq4, IC<0>{});
+        dq16_issue(dqr, (nqt + 1) & 1, IC<1>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dq16_land(dqr);
+        dq16_mma(dqr, dq4, IC<1>{});
+        asm volatile("s_nop 10" : "+v"(dq4));
+        dq16_commit(dq4, tprev);
+    } else {
+        dq_handover((nqt + 1) & 1, tprev);
+    }
     if constexpr (STAMP) {
         if (dbg && lane == 0) {
             unsigned int* o = dbg + (((long)b * gridDim.x + kb) * 4 + wave) * 8;
@@ -908,7 +1015,8 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
         else hipLaunchKernelGGL((pam_bwd_k64_kernel<6, false, 1, true, O_>), grid, dim3(256), 0, s, q, k, kT, v, dO, rc, Npad, dkn, dv, (void*)dq_scr, dk_bs, dv_bs, g_k64_dbg); \
         break;
         switch (g_k64_order == 1 ? 0 : g_k64_order == 2 ? 24 : g_k64_order == 3 ? 56 : g_k64_order == 4 ? 8
-                : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : g_k64_order == 7 ? 136 : g_k64_order == 8 ? 152 : -1) {
+                : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : g_k64_order == 7 ? 136 : g_k64_order == 8 ? 152
+                : g_k64_order == 9 ? 264 : g_k64_order == 10 ? 328 : -1) {
             K64_ORD(0)         // 1: the compiler-scheduled AGPR-form loop
             K64_ORD(8)         // 4: round-2 production (hand-placed dP phase)
             K64_ORD(24)        // 2: + unpacked dS multiplies
@@ -917,6 +1025,8 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
             K64_ORD(120)       // 6: hand-placed second half + segment stamps (diagnostic)
             K64_ORD(136)       // 7: production + first transpose reads hoisted above the dS arithmetic
             K64_ORD(152)       // 8: 7 + unpacked dS multiplies
+            K64_ORD(264)       // 9: production + DQ16 (dQ sub-tiles over all 256 keys, no cross-wave exchange)
+            K64_ORD(328)       // 10: 9 + segment stamps (diagnostic)
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD

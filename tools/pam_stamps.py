@@ -41,8 +41,8 @@ dv = torch.empty(B, Cp, Np, device=dev)
 K.pam_flash_fwd(qt, kt, vn, B, N, Np, C, Cp, gamma, x, out, o, lse, r_alg=r, v_ones=True)
 _, delta = K.chan_dot(do, o, gamma)
 names = ["wait+barrier", "head", "S+dP", "dS", "dV^T", "dK^T+dQ^T"]
-mfma = {5: [0, 4, 24, 0, 24, 8], 6: [0, 4, 24, 0, 24, 8]}
-for variant in (5, 6):
+mfma = {5: [0, 4, 24, 0, 24, 8], 6: [0, 4, 24, 0, 24, 8], 10: [0, 4, 28, 0, 24, 4]}
+for variant in [int(v) for v in os.environ.get("STAMP_VARIANTS", "5,6").split(",")]:
     dbg = torch.zeros(B * (Np // 256) * 4 * 8, device=dev, dtype=torch.int32)
     K.lib().gd_pam_k64_debug(dbg.data_ptr())
     K.lib().gd_pam_k64_variant(variant, 2)
@@ -60,7 +60,7 @@ for variant in (5, 6):
     per = d[:, :6] / tiles[:, None]
     mean = per.mean(0)
     tot = mean.sum().item()
-    print(f"variant {variant} ({'production schedule' if variant == 5 else 'hand-placed second half'} + stamps): "
+    print(f"variant {variant} ({ {5: 'production schedule', 6: 'hand-placed second half', 10: 'DQ16: dQ sub-tiles, no exchange'}[variant] } + stamps): "
           f"{e0.elapsed_time(e1):.2f} ms, {tot:.0f} cycles per tile and wave (MFMA: 60 x 32 = 1920)")
     for n, c, m in zip(names, mean.tolist(), mfma[variant]):
         print(f"    {n:14s} {c:8.1f} cycles  ({100 * c / tot:5.1f} %)   MFMA cycles issued in it: {32 * m}")
