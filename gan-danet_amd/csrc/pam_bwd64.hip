@@ -532,6 +532,10 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     dma_next(tpf, 1);
     tpf = next_tile(tpf);
 
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (STAMP) {           // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz over the whole sweep
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
+    }
     for (int it = 0; it < nqt; ++it) {
         // tile `it` landed: this wave's pieces by its own counted wait, the other waves' by the barrier behind it.
         // Younger VMEM operations than DMA(it): [hand-over(it-3)] DMA(it+1) [hand-over(it-2)]
@@ -917,11 +921,16 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     }
     if constexpr (STAMP) {
         if (dbg && lane == 0) {
-            unsigned int* o = dbg + (((long)b * gridDim.x + kb) * 4 + wave) * 8;
+            unsigned long long clk1, rt1;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1), "=s"(rt1) :: "memory");
+            unsigned int* o = dbg + (((long)b * gridDim.x + kb) * 4 + wave) * 12;
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[k] = sacc_t[k];
             o[6] = sacc_w;
             o[7] = (unsigned int)(nqt - 2);
+            o[8] = (unsigned int)(clk1 - clk0);
+            o[9] = (unsigned int)(rt1 - rt0);
+            o[10] = o[11] = 0;
         }
     }
 

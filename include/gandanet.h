@@ -377,7 +377,7 @@ size_t gd_pam_bwd_scratch_bytes(int Npad, int form);
 /* tuning hook (bench tooling; process-global, not thread safe): schedule variant of the K64 kernel (0 = production)
  * and the number of a wave's two key tiles whose V rows stay in registers (1 or 2; 0 = default). */
 void gd_pam_k64_variant(int order, int vreg);
-/* diagnostic variants 5 / 6 only (tools/pam_stamps.py): device buffer of images x key blocks x 4 waves x 8 uint32 that
+/* diagnostic variants 5 / 6 only (tools/pam_stamps.py): device buffer of images x key blocks x 4 waves x 12 uint32 that
  * receives the per-wave cycle sums of the tile loop's segments; NULL (default) = no output */
 void gd_pam_k64_debug(void* buf);
 int gd_pam_flash_bwd(const void* qt, const void* kt, const void* kn, const void* vt, const void* dot_,

@@ -1,0 +1,103 @@
+// Microbenchmark (round 3): do the two bf16 MFMA shapes deliver the same FLOP/s under load?  The PAM kernels turned out to be
+// power-managed (cycle savings come back as a lower clock), and the guide reports v_mfma_f32_16x16x32_bf16 at
+// ~1.15x the FLOP/s of v_mfma_f32_32x32x16_bf16 in bare loops at equal cycles per FLOP.  Here: one wave per SIMD (256
+// threads, 96 KiB LDS per workgroup), register operands, pseudo-random data, same output tile per wave (32 x 128:
+// 4 accumulators of 32x32 or 16 of 16x16), optional exp fillers (the softmax share of an attention tile: 1 v_exp per MFMA
+// of 32x32x16-equivalent work per 2 gaps).  Reports wall TF, cycles per 32x32x16-equivalent MFMA and the in-kernel clock
+// (d s_memtime / d s_memrealtime x 100 MHz).
+// hipcc --offload-arch=gfx950 -O3 -o mfma_shape mfma_shape.hip && ./mfma_shape
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int SHAPE, int NEXP>
+__global__ __launch_bounds__(256, 1) void kern(float* out, unsigned long long* st, int iters) {
+    extern __shared__ char lds_force[];
+    bf16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            a[i][e] = (__bf16)(((threadIdx.x * 37 + e * 11 + i * 5) % 97) * 0.02f - 0.9f);
+            b[i][e] = (__bf16)(((threadIdx.x * 13 + e * 29 + i * 7) % 89) * 0.02f - 0.8f);
+        }
+    f32x16 acc32[4];
+    f32x4 acc16[16];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) acc16[i][e] = 0.f;
+    float v[8];
+    for (int e = 0; e < 8; ++e) v[e] = -0.001f * threadIdx.x - e;
+    unsigned long long c0, r0, c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0) :: "memory");
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (SHAPE == 32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc32[i]) : "v"(a[i]), "v"(b[(i + 1) & 3]));
+#pragma unroll
+                for (int e = 0; e < NEXP; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(2 * i + e) & 7]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {      // 4 MFMAs of 16x16x32 = the FLOPs of ONE 32x32x16... x2 in K: 16*16*32*2 vs 32*32*16*2 -> 2 per
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[i]) : "v"(a[i & 3]), "v"(b[(i + 1) & 3]));
+                if ((i & 1) == 1) {
+#pragma unroll
+                    for (int e = 0; e < NEXP; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i + e) & 7]));
+                }
+            }
+        }
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc32[i][e];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) s += acc16[i][e];
+    for (int e = 0; e < 8; ++e) s += v[e];
+    out[blockIdx.x * 256 + threadIdx.x] = s + (lds_force[threadIdx.x] ? 0.f : 0.f);
+    if ((threadIdx.x & 63) == 0) {
+        st[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = c1 - c0;
+        st[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int SHAPE, int NEXP>
+void run(float* d, unsigned long long* ds, int iters) {
+    hipFuncSetAttribute((const void*)kern<SHAPE, NEXP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) kern<SHAPE, NEXP><<<256, 256, 96 * 1024>>>(d, ds, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kern<SHAPE, NEXP><<<256, 256, 96 * 1024>>>(d, ds, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(2048);
+    hipMemcpy(h.data(), ds, 2048 * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc, clk;
+    for (int i = 0; i < 1024; ++i) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    const double flop = 256.0 * 4 * (double)iters * (SHAPE == 32 ? 4.0 * 32 * 32 * 16 * 2 : 16.0 * 16 * 16 * 32 * 2);
+    const double per32 = cyc[512] / ((double)iters * (SHAPE == 32 ? 4.0 : 8.0));
+    printf("  %dx%d MFMA, %d v_exp per 32x32x16-equivalent: %7.3f ms  %6.0f TF  %5.1f cycles per 32x32x16-equivalent  clock %.3f GHz\n",
+           SHAPE, SHAPE, NEXP, ms, flop / (ms * 1e-3) / 1e12, per32, clk[512]);
+}
+
+int main() {
+    float* d; unsigned long long* ds;
+    hipMalloc(&d, 256 * 256 * 4);
+    hipMalloc(&ds, 2048 * 8);
+    const int iters = 40000;
+    printf("bf16 MFMA shapes under load: 256 workgroups x 4 waves (one per SIMD), register operands, random data\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        run<32, 0>(d, ds, iters);
+        run<16, 0>(d, ds, iters / 2);
+        run<32, 1>(d, ds, iters);
+        run<16, 1>(d, ds, iters / 2);
+        run<32, 2>(d, ds, iters);
+        run<16, 2>(d, ds, iters / 2);
+    }
+    return 0;
+}

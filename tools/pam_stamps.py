@@ -43,7 +43,7 @@ _, delta = K.chan_dot(do, o, gamma)
 names = ["wait+barrier", "head", "S+dP", "dS", "dV^T", "dK^T+dQ^T"]
 mfma = {5: [0, 4, 24, 0, 24, 8], 6: [0, 4, 24, 0, 24, 8], 10: [0, 4, 28, 0, 24, 4]}
 for variant in [int(v) for v in os.environ.get("STAMP_VARIANTS", "5,6").split(",")]:
-    dbg = torch.zeros(B * (Np // 256) * 4 * 8, device=dev, dtype=torch.int32)
+    dbg = torch.zeros(B * (Np // 256) * 4 * 12, device=dev, dtype=torch.int32)
     K.lib().gd_pam_k64_debug(dbg.data_ptr())
     K.lib().gd_pam_k64_variant(variant, 2)
     for _ in range(2):
@@ -55,7 +55,7 @@ for variant in [int(v) for v in os.environ.get("STAMP_VARIANTS", "5,6").split(",
     torch.cuda.synchronize()
     K.lib().gd_pam_k64_variant(0, 0)
     K.lib().gd_pam_k64_debug(None)
-    d = dbg.view(-1, 8).double().cpu()
+    d = dbg.view(-1, 12).double().cpu()
     tiles = d[:, 7]
     per = d[:, :6] / tiles[:, None]
     mean = per.mean(0)
@@ -66,5 +66,7 @@ for variant in [int(v) for v in os.environ.get("STAMP_VARIANTS", "5,6").split(",
         print(f"    {n:14s} {c:8.1f} cycles  ({100 * c / tot:5.1f} %)   MFMA cycles issued in it: {32 * m}")
     w = per.view(-1, 4, 6).mean(0)
     print("    by wave (wait+barrier): " + "  ".join(f"{w[i, 0].item():.0f}" for i in range(4)))
+    clk = (d[:, 8] / d[:, 9].clamp(min=1)).median().item() * 100.0          # s_memrealtime ticks at 100 MHz
+    print(f"    in-kernel clock over the sweep (median wave): {clk / 1000:.3f} GHz")
     wq = (d[:, 6] / tiles).view(-1, 4).mean(0)
     print("      of which loop back + counted vmcnt / lgkmcnt waits (before the barrier), by wave: " + "  ".join(f"{v.item():.0f}" for v in wq))
