@@ -780,3 +780,61 @@ def test_conv3x3_split_bf16_vs_fp64(gd, case):
     with gd.precision("bf16"):
         yb = ops.conv2d(xb, w.to(DEV), None if b is None else b.to(DEV), 1, 1, ops.ACT_RELU if relu else ops.ACT_NONE)
     assert relmax(yb, yr.float()) > 20 * relmax(y, yr.float())
+
+
+def test_syncbn_kernels_merge_of_two_shards_equals_full_batch(gd):
+    """SyncBN's kernels without torch.distributed: the (count, mean, M2) records of two unequal shards, stacked as the
+    all-gather would deliver them, merge (gd_bn_stats_merge) to the statistics gd_bn_stats takes on the whole batch
+    -- mean, invstd, running statistics -- and gd_bn_act_bwd_dx on a shard with the summed dy sums and the global count
+    equals the shard's rows of the full-batch backward."""
+    _, K = _ops()
+    B, C, H, W = 5, 24, 12, 16
+    x = (seeded((B, C, H, W), 71) * 2.0 + 0.7).to(DEV)
+    dy = seeded((B, C, H, W), 72).to(DEV)
+    gamma, beta = (seeded((C,), 73) * 0.3 + 1.0).to(DEV), seeded((C,), 74, 0.2).to(DEV)
+    eps, mom = 1e-5, 0.1
+    rm_a, rv_a = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm_b, rv_b = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd = K.bn_stats(x, eps, mom, rm_a, rv_a)
+    shards = (x[:2].contiguous(), x[2:].contiguous())
+    recs = torch.stack([K.bn_stats_local(s_) for s_ in shards], 0)            # (2, C, 3): unequal counts 2 and 3 images
+    assert recs.shape == (2, C, 3) and recs[0, 0, 0].item() == 2 * H * W and recs[1, 0, 0].item() == 3 * H * W
+    m2, is2 = K.bn_stats_merge(recs.contiguous(), eps, mom, rm_b, rv_b)
+    assert_close(m2, mean, 1e-6, "merged mean")
+    assert_close(is2, invstd, 1e-6, "merged invstd")
+    assert_close(rm_b, rm_a, 1e-6, "running mean")
+    assert_close(rv_b, rv_a, 1e-6, "running var (unbiased, global count)")
+    scale, shift = K.bn_fold(gamma, beta, mean, invstd)
+    dg, db, dx = K.bn_act_bwd(dy, x, scale, shift, mean, invstd, 1, True)
+    sums = torch.zeros(2, C, device=DEV)
+    for lo, hi in ((0, 2), (2, 5)):
+        part = torch.empty(2, C, device=DEV)
+        K.bn_act_bwd(dy[lo:hi].contiguous(), x[lo:hi].contiguous(), scale, shift, mean, invstd, 1, True, want_dx=False, sums_out=part)
+        sums += part                                                             # the all-reduce (test plumbing)
+    assert_close(sums[0], dg, 1e-5, "summed dgamma")
+    assert_close(sums[1], db, 1e-5, "summed dbeta")
+    for lo, hi in ((0, 2), (2, 5)):
+        dxs = K.bn_act_bwd_dx(dy[lo:hi].contiguous(), x[lo:hi].contiguous(), scale, shift, mean, invstd, sums[0], sums[1],
+                              1.0 / (B * H * W), 1)
+        assert_close(dxs, dx[lo:hi].cpu(), 1e-5, f"dx of shard {lo}:{hi}")
+
+
+def test_pam_f16_scale_is_a_power_of_two_and_fills_the_range(gd):
+    """gd_pam_f16_scale: scales[0] = gamma * 2^k, scales[1] = 2^-k with max |gamma * 2^k * dOut| in [0.5, 1); delta is
+    multiplied by 2^k in place; an all-zero gradient leaves k = 0"""
+    _, K = _ops()
+    for amp in (3e-9, 1.0, 7e4):
+        do = (seeded((2, 16, 8, 8), 81) * amp).to(DEV)
+        gamma = torch.full((1,), 0.3, device=DEV)
+        delta = seeded((2, 64), 82).to(DEV)
+        d0 = delta.clone()
+        sc = K.pam_f16_scale(do, gamma, delta).cpu()
+        up = sc[0].item() / 0.3
+        assert abs(up * sc[1].item() - 1.0) < 1e-6
+        assert abs(round(torch.log2(torch.tensor(up)).item()) - torch.log2(torch.tensor(up)).item()) < 1e-5, "not a power of two"
+        top = (do.abs().max().item() * 0.3) * up
+        assert 0.5 <= top < 1.0, top
+        assert_close(delta, d0.cpu() * up, 1e-6, "delta scaled in place")
+    do = torch.zeros(1, 8, 4, 4, device=DEV)
+    sc = K.pam_f16_scale(do, torch.full((1,), 0.3, device=DEV), torch.zeros(1, 16, device=DEV)).cpu()
+    assert abs(sc[0].item() - 0.3) < 1e-7 and sc[1].item() == 1.0
