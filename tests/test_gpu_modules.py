@@ -888,9 +888,12 @@ def test_generator_eval_forward_inference_tiles_vs_oracle(gd, shape):
             y32 = G(x.to(DEV))
         with gd.precision("bf16"):
             y16 = G(x.to(DEV))
+        with gd.precision("mixed"):       # 45 x 22: H*W % 8 != 0 -> the split-bf16 route declines, exact convs; 88 x 60: split-bf16
+            ymx = G(x.to(DEV))
     assert tuple(y32.shape) == (shape[0], 1, 4 * shape[2], 4 * shape[3])
     assert_close(y32, yo, 1e-3, "eval forward fp32")
     assert_close(y16, yo, 5e-2, "eval forward bf16", rell2)
+    assert_close(ymx, yo, 1e-3, "eval forward mixed (north star 1e-3, ragged PAM)")
 
 
 def test_pam_flash_backward_forms_agree_at_bench_and_max_size(gd):

@@ -1,7 +1,7 @@
 """K64 backward, DQ16 variant (gd_pam_k64_variant 9) against the production schedule (variant 4) on one small case: dK / dV must be
 bit-identical, dQ equal to fp32 round-off (different summation order).  python tools/k64_dq16_check.py"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gan_danet_amd import kern as K
 dev = torch.device("cuda")

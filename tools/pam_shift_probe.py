@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gan_danet_amd as gd
 from gan_danet_amd import kern as K
