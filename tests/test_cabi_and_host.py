@@ -134,3 +134,44 @@ def test_batch_plan_gives_every_rank_the_same_steps():
     assert DeviceTileDataset.batch_plan(_Fake(), 32, 0, 1)[-1] == (96, 100)
     with pytest.raises(ValueError):
         DeviceTileDataset.batch_plan(_Fake(), 30, 0, 8)
+
+
+def test_operand_modes_per_layer_class():
+    """host logic of the precision modes (config.operand_mode): which MFMA operand form each layer class takes, the
+    per-class override used by tools/parity_attribution.py, and the environment form of the override"""
+    import importlib
+    cfg = importlib.import_module("gan_danet_amd.config")        # (the package attribute `config` is the settings object)
+    saved = (cfg.config.precision, dict(cfg.config.override))
+    try:
+        cfg.config.override.clear()
+        table = {
+            "bf16": {"pam": "16", "dense3x3": "16", "conv1x1": "16", "vgg": "16", "disc": "16", "stem": "exact"},
+            "fp16": {"pam": "16", "dense3x3": "16", "stem": "exact"},
+            "fp32": {"pam": "exact", "dense3x3": "exact", "vgg": "exact", "stem": "exact"},
+            "mixed": {"pam": "16", "dense3x3": "x3", "fuse3x3": "x3", "decoder": "x3", "vgg": "x3", "conv1x1": "exact",
+                      "cam_apply": "exact", "disc": "exact", "stem": "exact", "other": "exact"},
+        }
+        for prec, want in table.items():
+            with cfg.precision(prec):
+                for layer, mode in want.items():
+                    assert cfg.operand_mode(layer) == mode, (prec, layer, cfg.operand_mode(layer))
+                assert cfg.sixteen_bit("pam") == (prec != "fp32")
+        with cfg.precision("bf16"), cfg.layer_override(dense3x3="exact", stem="16"):
+            assert cfg.operand_mode("dense3x3") == "exact" and cfg.operand_mode("stem") == "16" and cfg.operand_mode("vgg") == "16"
+        assert cfg.operand_mode("dense3x3") == "16"                      # the override is scoped
+        for bad in ({"nosuchclass": "exact"}, {"vgg": "fp64"}):
+            try:
+                with cfg.layer_override(**bad):
+                    pass
+                raise AssertionError("layer_override accepted " + str(bad))
+            except ValueError:
+                pass
+        try:
+            cfg.set_precision("fp8")
+            raise AssertionError("set_precision accepted fp8")
+        except ValueError:
+            pass
+    finally:
+        cfg.config.precision = saved[0]
+        cfg.config.override.clear()
+        cfg.config.override.update(saved[1])
