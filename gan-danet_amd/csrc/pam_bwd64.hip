@@ -224,6 +224,13 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     // four images, B = the K rows of the 256 keys, held in registers) and adds it straight to dQ -- no fp32 exchange
     // buffer, no 16 single-dword reads and 12 adds per tile, no LDS write in front of the barrier.
     constexpr bool DQ16 = (ORDER & 256) != 0;
+    // bit 9 (DV16): the dV^T and dK^T products (28 of the 60 MFMA-equivalents of a tile) on v_mfma_f32_16x16x32: the P / dS
+    // fragments of a key tile are regrouped with v_permlane16_swap (8 + 8 per tile) into the B operands of its two 16-key
+    // halves, the dO^T / Q^T operands come from the same transpose reads with other row addresses, the accumulators
+    // become 16 x 16 tiles (same register count).  The kernel is power-managed: the 16-wide shape costs the
+    // same cycles and less energy per FLOP.
+    constexpr bool DV16 = (ORDER & 512) != 0;
+    constexpr bool DV16_V = DV16 && !(ORDER & 2048), DV16_K = DV16 && !(ORDER & 1024);   // A/B: one product only
     constexpr int OFF_X = NSLOT * SLOT;
     constexpr int OFF_XQ = OFF_X + (DQ16 ? 2 : 1) * 4 * XW;
     constexpr int XQ_BUF = 4 * 32 * QXLD;          // floats per exchange buffer
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     constexpr bool PH2 = (ORDER & 32) != 0;
     static_assert(!PH2 || VFORM, "the hand-placed second half continues the hand-placed dP phase");
     static_assert(!DQ16 || (VFORM && !PH2 && CT >= 4), "DQ16 rides in the hand-placed dP phase of the production schedule (>= 8 steps)");
+    static_assert(!DV16 || (VFORM && !PH2 && !DQ_FIRST), "DV16 replaces the compiler-scheduled dV^T / dK^T steps of the production schedule");
     // bit 6 (diagnostic build only, tools/pam_stamps.py): s_memtime stamps at the segment seams of the tile loop; the
     // values are requested without a wait (SMEM returns through lgkmcnt: the loop-top lgkmcnt(0) covers them) and summed
     // per wave into dbg[(image, key block, wave)][8] = {wait+barrier, head, S+dP, dS, dV^T, dK^T+dQ^T, -, tiles}
@@ -375,6 +383,18 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     };
 
+    // DV16: 16 x 16 accumulator tiles [channel tile][16-channel half][key tile][16-key half] / [16-d half][key tile][half]
+    f32x4_acc_t dv16[DV16 ? CT : 1][2][2][2], dk16[2][2][2];
+#pragma unroll
+    for (int a_ = 0; a_ < (DV16 ? CT : 1); ++a_)
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv16[a_][i_ >> 2][(i_ >> 1) & 1][i_ & 1][e] = 0.f;
+#pragma unroll
+    for (int i_ = 0; i_ < 8; ++i_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dk16[i_ >> 2][(i_ >> 1) & 1][i_ & 1][e] = 0.f;
     f32x16_t dvacc[2][CT], dkacc[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -404,6 +424,15 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
     const int off_trd_lo = (4 * h + (li >> 2)) * DOLD + ((c2 ^ h) << 3) + 4 * (li & 1);            // dO^T: + 16 s DOLD + 32 ct
     const int off_trd_hi = (4 * h + (li >> 2) + 8) * DOLD + ((c2 ^ (h + 2)) << 3) + 4 * (li & 1);  //   rows + 8: swizzle h + 2
     const int off_trq = (4 * h + (li >> 2)) * B_QLD + 16 * g4 + 4 * (li & 3);                      // Q^T: + 16 s B_QLD (+ 8 B_QLD)
+    // DV16: the A operand (16 rows x 32 queries) of a 16x16x32 MFMA by two transpose reads whose row addresses follow the
+    // slot order of the regrouped P / dS fragments: lane group g = lane >> 4 takes the queries 16 (g & 1) + 4 (g >> 1) + {0..3}
+    // (first read) and + 8 (second read); the chunk swizzle of the dO image is (row >> 2) & 3 = g >> 1 resp. (g >> 1) + 2
+    const int row16 = 16 * ((lane >> 4) & 1) + 4 * (lane >> 5) + (li >> 2), p16 = li & 3, hh16 = lane >> 5;
+    const int off16_d1[2] = {row16 * DOLD + (((0 + (p16 >> 1)) ^ hh16) << 3) + 4 * (p16 & 1),
+                             row16 * DOLD + (((2 + (p16 >> 1)) ^ hh16) << 3) + 4 * (p16 & 1)};
+    const int off16_d2[2] = {(row16 + 8) * DOLD + (((0 + (p16 >> 1)) ^ (hh16 + 2)) << 3) + 4 * (p16 & 1),
+                             (row16 + 8) * DOLD + (((2 + (p16 >> 1)) ^ (hh16 + 2)) << 3) + 4 * (p16 & 1)};
+    const int off16_q1 = row16 * B_QLD + 4 * p16, off16_q2 = (row16 + 8) * B_QLD + 4 * p16;      // + 16 (d half)
     const unsigned short* x_tr = Xw + (4 * h + (li >> 2)) * XLD + 16 * g4 + 4 * (li & 3);          // dS^T: + 32 k2 XLD + 16 s XLD
     unsigned short* x_wr = Xw + r * XLD + 4 * h;
     const unsigned short* v_rows = Vw + r * DLD + 8 * h;
@@ -758,9 +787,22 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         const unsigned int a_dlo = lds_addr(do_tr_lo), a_dhi = lds_addr(do_tr_hi);
         const unsigned int a_q = lds_addr(q_tr), a_x = lds_addr(x_tr);
         TrFrag2 fb[CT + 3];
+        const unsigned int a16_d1[2] = {lds_addr(dOs + off16_d1[0]), lds_addr(dOs + off16_d1[1])};
+        const unsigned int a16_d2[2] = {lds_addr(dOs + off16_d2[0]), lds_addr(dOs + off16_d2[1])};
+        const unsigned int a16_q1 = lds_addr(Qs + off16_q1), a16_q2 = lds_addr(Qs + off16_q2);
         auto issue = [&](auto idc) {
             constexpr int id = decltype(idc)::value;
-            if constexpr (id < CT) fb[id] = tr_issue2<id * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
+            if constexpr (DV16_V && id < CT) {            // lo0 / hi0: channels 32 id + 0..15, lo1 / hi1: + 16..31
+                fb[id].lo0 = tr_issue<id * 64>(a16_d1[0]);
+                fb[id].hi0 = tr_issue<id * 64>(a16_d2[0]);
+                fb[id].lo1 = tr_issue<id * 64>(a16_d1[1]);
+                fb[id].hi1 = tr_issue<id * 64>(a16_d2[1]);
+            } else if constexpr (DV16_K && id == CT) {    // Q^T: d 0..15 / 16..31
+                fb[id].lo0 = tr_issue<0>(a16_q1);
+                fb[id].hi0 = tr_issue<0>(a16_q2);
+                fb[id].lo1 = tr_issue<32>(a16_q1);
+                fb[id].hi1 = tr_issue<32>(a16_q2);
+            } else if constexpr (id < CT) fb[id] = tr_issue2<id * 64, 16 * DOLD * 2>(a_dlo, a_dhi);
             else if constexpr (id == CT) fb[id] = tr_issue2<0, 16 * B_QLD * 2>(a_q, a_q + 8 * B_QLD * 2);
             else fb[id] = tr_issue2<(id - CT - 1) * 32 * XLD * 2, 16 * XLD * 2>(a_x, a_x + 8 * XLD * 2);
         };
@@ -805,7 +847,15 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
                 dsf[k2][q >> 1] = __builtin_bit_cast(bf16x8_t, w);
             }
         };
+        if constexpr (DV16_V) {                           // P of each key tile -> the B operands of its two 16-key halves
+            swap16_frags(pf[0][0], pf[0][1]);
+            swap16_frags(pf[1][0], pf[1][1]);
+        }
         if constexpr (!PH2) static_for<0, 8>(ds_chunk);
+        if constexpr (DV16_K) {                           // dS likewise (the dS^T image above was written from the plain words)
+            swap16_frags(dsf[0][0], dsf[0][1]);
+            swap16_frags(dsf[1][0], dsf[1][1]);
+        }
         stamp(IC<4>{});
         f32x16_t dqp;
 #pragma unroll
@@ -813,7 +863,19 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         auto compute = [&](auto idc) {
             constexpr int id = decltype(idc)::value;
             const bf16x8_t a0 = tr_frag(fb[id].lo0, fb[id].hi0), a1 = tr_frag(fb[id].lo1, fb[id].hi1);
-            if constexpr (id < CT) {
+            if constexpr (DV16_V && id < CT) {
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_) {        // (key tile, half): eight 16-cycle MFMAs on eight accumulators
+                    dv16[id][0][i_ >> 1][i_ & 1] = mfma16x16<F16>(a0, pf[i_ >> 1][i_ & 1], dv16[id][0][i_ >> 1][i_ & 1]);
+                    dv16[id][1][i_ >> 1][i_ & 1] = mfma16x16<F16>(a1, pf[i_ >> 1][i_ & 1], dv16[id][1][i_ >> 1][i_ & 1]);
+                }
+            } else if constexpr (DV16_K && id == CT) {
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_) {
+                    dk16[0][i_ >> 1][i_ & 1] = mfma16x16<F16>(a0, dsf[i_ >> 1][i_ & 1], dk16[0][i_ >> 1][i_ & 1]);
+                    dk16[1][i_ >> 1][i_ & 1] = mfma16x16<F16>(a1, dsf[i_ >> 1][i_ & 1], dk16[1][i_ >> 1][i_ & 1]);
+                }
+            } else if constexpr (id < CT) {
                 dvacc[0][id] = mfma16<F16>(a0, pf[0][0], dvacc[0][id]);
                 dvacc[1][id] = mfma16<F16>(a0, pf[1][0], dvacc[1][id]);
                 dvacc[0][id] = mfma16<F16>(a1, pf[0][1], dvacc[0][id]);
@@ -934,15 +996,36 @@ __global__ __launch_bounds__(256, 1) void pam_bwd_k64_kernel(
         }
     }
 
+    if constexpr (DV16) {
+        // 16 x 16 tiles: row 4 (lane >> 4) + e = channel (d) inside the 16-block, column lane & 15 = key inside the half
+        const int g16 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) {
+            const int j = j0 + 32 * (i_ >> 1) + 16 * (i_ & 1) + c16;
+#pragma unroll
+            for (int ct = 0; ct < (DV16_V ? CT : 0); ++ct)
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dv[(long)b * dv_bs + (long)(ct * 32 + 16 * cp + 4 * g16 + e) * Npad + j] = dv16[ct][cp][i_ >> 1][i_ & 1][e];
+#pragma unroll
+            for (int db = 0; db < (DV16_K ? 2 : 0); ++db)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dkn[(long)b * dk_bs + (long)(16 * db + 4 * g16 + e) * Npad + j] = dk16[db][i_ >> 1][i_ & 1][e] * LN2;
+        }
+    }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         const int j = j0 + 32 * k2 + r;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < (DV16_V ? 0 : CT); ++ct)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dv[(long)b * dv_bs + (long)(ct * 32 + acc_row(e, h)) * Npad + j] = dvacc[k2][ct][e];
+        if constexpr (!DV16_K)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dkn[(long)b * dk_bs + (long)acc_row(e, h) * Npad + j] = dkacc[k2][e] * LN2;   // Q^T was q * log2 e
+            for (int e = 0; e < 16; ++e) dkn[(long)b * dk_bs + (long)acc_row(e, h) * Npad + j] = dkacc[k2][e] * LN2;   // Q^T was q * log2 e
     }
 }
 
@@ -1025,7 +1108,8 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
         break;
         switch (g_k64_order == 1 ? 0 : g_k64_order == 2 ? 24 : g_k64_order == 3 ? 56 : g_k64_order == 4 ? 8
                 : g_k64_order == 5 ? 72 : g_k64_order == 6 ? 120 : g_k64_order == 7 ? 136 : g_k64_order == 8 ? 152
-                : g_k64_order == 9 ? 264 : g_k64_order == 10 ? 328 : -1) {
+                : g_k64_order == 9 ? 264 : g_k64_order == 10 ? 328 : g_k64_order == 11 ? 520
+                : g_k64_order == 14 ? 1544 : g_k64_order == 15 ? 2568 : -1) {
             K64_ORD(0)         // 1: the compiler-scheduled AGPR-form loop
             K64_ORD(8)         // 4: round-2 production (hand-placed dP phase)
             K64_ORD(24)        // 2: + unpacked dS multiplies
@@ -1036,6 +1120,11 @@ extern "C" int gd_pam_bwd64_slice(const void* qt, const void* kt, const void* kn
             K64_ORD(152)       // 8: 7 + unpacked dS multiplies
             K64_ORD(264)       // 9: production + DQ16 (dQ sub-tiles over all 256 keys, no cross-wave exchange)
             K64_ORD(328)       // 10: 9 + segment stamps (diagnostic)
+            // DV16 (measured 8 % SLOWER than production, profiles/r03_k64_dv16_ab.txt; the DQ16 + DV16 combination computes a
+            // wrong dS for the first tile of a workgroup -- unresolved, not instantiated)
+            K64_ORD(520)       // 11: production + DV16 (dV^T / dK^T on 16x16x32 MFMAs)
+            K64_ORD(1544)      // 14: DV16 for dV^T only
+            K64_ORD(2568)      // 15: DV16 for dK^T only
             default: gd_set_error("gd_pam_k64_variant: unknown order"); return -1;
         }
 #undef K64_ORD

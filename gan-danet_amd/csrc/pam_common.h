@@ -29,6 +29,33 @@ __device__ __forceinline__ f32x16_t mfma16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
                                                        __builtin_bit_cast(bf16x8_native_t, b), c, 0, 0, 0);
 }
 
+// D = A B + C on 16x16x32 tiles (A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], D[row 4(l>>4)+e][col l&15]): the
+// shape that draws less power per FLOP under load (tools/micro/mfma_shape.hip: +8..13 % FLOP/s in bare loops)
+typedef float f32x4_acc_t __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ f32x4_acc_t mfma16x16(bf16x8_t a, bf16x8_t b, f32x4_acc_t c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_native_t, a),
+                                                      __builtin_bit_cast(f16x8_native_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_native_t, a),
+                                                       __builtin_bit_cast(bf16x8_native_t, b), c, 0, 0, 0);
+}
+// v_permlane16_swap on every dword of two fragments: x <- [x.row0, y.row0, x.row2, y.row2], y <- [x.row1, y.row1, x.row3,
+// y.row3] (rows = 16-lane groups).  For the two k-step fragments of a 32x32 accumulator tile (lane = column r, half h)
+// this gathers the columns 0..15 into x and 16..31 into y, each with its 32 k values spread over the four lane groups:
+// the B operand of a 16x16x32 MFMA over those 16 columns (slot t of group g <-> row 16 (g&1) + 8 (t>>2) + 4 (g>>1) + (t&3)).
+__device__ __forceinline__ void swap16_frags(bf16x8_t& x, bf16x8_t& y) {
+    // one volatile asm statement: the scheduler would otherwise move the swaps up into hand-placed MFMA phases (whose asm
+    // MFMAs it cannot see the hazards of); s_nop 1 = the two wait states between a VALU write and a permlane swap of it
+    u32x4_t a = __builtin_bit_cast(u32x4_t, x), b = __builtin_bit_cast(u32x4_t, y);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    x = __builtin_bit_cast(bf16x8_t, a);
+    y = __builtin_bit_cast(bf16x8_t, b);
+}
+
 // two floats -> one dword of two 16-bit values (lo in bits 0..15), round to nearest even
 template <bool F16>
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {

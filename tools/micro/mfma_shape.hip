@@ -39,6 +39,27 @@ __global__ __launch_bounds__(256, 1) void kern(float* out, unsigned long long* s
 #pragma unroll
                 for (int e = 0; e < NEXP; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(2 * i + e) & 7]));
             }
+        } else if constexpr (SHAPE == 48) {
+            // the mix a partial conversion of the K64 backward would run: 8 of 15 MFMA-equivalents stay 32x32x16 (S, dP,
+            // dQ^T), 7 become 16x16x32 pairs (dV^T, dK^T); reference = SHAPE 47: the same 15 equivalents all 32x32x16
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc32[i & 3]) : "v"(a[i & 3]), "v"(b[(i + 1) & 3]));
+#pragma unroll
+                for (int e = 0; e < NEXP; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i + e) & 7]));
+            }
+#pragma unroll
+            for (int i = 0; i < 14; ++i)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[i]) : "v"(a[i & 3]), "v"(b[(i + 1) & 3]));
+        } else if constexpr (SHAPE == 47) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc32[i & 3]) : "v"(a[i & 3]), "v"(b[(i + 1) & 3]));
+                if (i < 8) {
+#pragma unroll
+                    for (int e = 0; e < NEXP; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i + e) & 7]));
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {      // 4 MFMAs of 16x16x32 = the FLOPs of ONE 32x32x16... x2 in K: 16*16*32*2 vs 32*32*16*2 -> 2 per
@@ -79,8 +100,9 @@ void run(float* d, unsigned long long* ds, int iters) {
     std::vector<double> cyc, clk;
     for (int i = 0; i < 1024; ++i) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-    const double flop = 256.0 * 4 * (double)iters * (SHAPE == 32 ? 4.0 * 32 * 32 * 16 * 2 : 16.0 * 16 * 16 * 32 * 2);
-    const double per32 = cyc[512] / ((double)iters * (SHAPE == 32 ? 4.0 : 8.0));
+    const double eq = SHAPE == 32 ? 4.0 : (SHAPE == 16 ? 8.0 : 15.0);      // 32x32x16-equivalent MFMAs per iteration
+    const double flop = 256.0 * 4 * (double)iters * eq * 32 * 32 * 16 * 2;
+    const double per32 = cyc[512] / ((double)iters * eq);
     printf("  %dx%d MFMA, %d v_exp per 32x32x16-equivalent: %7.3f ms  %6.0f TF  %5.1f cycles per 32x32x16-equivalent  clock %.3f GHz\n",
            SHAPE, SHAPE, NEXP, ms, flop / (ms * 1e-3) / 1e12, per32, clk[512]);
 }
@@ -98,6 +120,10 @@ int main() {
         run<16, 1>(d, ds, iters / 2);
         run<32, 2>(d, ds, iters);
         run<16, 2>(d, ds, iters / 2);
+        run<47, 2>(d, ds, iters / 4);
+        run<48, 2>(d, ds, iters / 4);
+        run<47, 4>(d, ds, iters / 4);
+        run<48, 4>(d, ds, iters / 4);
     }
     return 0;
 }
