@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgandanet_hip.so")
 
-PREC_FP32, PREC_BF16, PREC_FP16 = 0, 1, 2   # PREC_FP16: fp16 operands in the fused PAM kernels, bf16 elsewhere
+PREC_FP32, PREC_BF16, PREC_X3 = 0, 1, 2   # GD_PREC_*: exact f32 MFMA / bf16 operands / split-bf16 (hi + lo, three MFMAs per product)
 PAM_BWD_K64_ATOMIC, PAM_BWD_K64_PARTS, PAM_BWD_K32_PARTS, PAM_BWD_TWO_KERNEL = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
 

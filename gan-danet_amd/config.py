@@ -9,8 +9,10 @@ PRECISIONS = ("bf16", "fp16", "fp32", "mixed")
 
 # layer classes whose operand type can be overridden one at a time (tools/parity_attribution.py: error attribution)
 LAYER_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "pam", "stem", "disc", "vgg", "other")
-# classes served by the split-bf16 ("x3") route of the pixel-major 3x3 kernels under "mixed"; the others run exact f32 MFMA
-X3_CLASSES = ("dense3x3", "fuse3x3", "decoder", "vgg")
+# classes on split-bf16 ("x3") operands under "mixed": 3x3 / stride-1 convs through the pixel-major kernels on [hi | lo | hi]
+# packs, everything else through the generic conv / GEMM kernels, which split their fp32 operands while staging them
+# (GD_PREC_X3); the stem (and nn.Linear, HBM-bound) stays on the exact f32 MFMA
+X3_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "disc", "vgg", "other")
 
 
 @dataclass
@@ -23,7 +25,7 @@ class _Config:
     #           N x N matrices: small tiles only);
     #   "mixed" the mode that holds the north-star 1e-3 AT the benchmark size: the fused flash PAM (fp16 operands, fp32
     #           accumulate / softmax statistics) and every other product in split-bf16 ("x3": hi*hi + lo*hi + hi*lo,
-    #           2^-16 relative) or exact f32 MFMA.
+    #           2^-16 relative); exact f32 MFMA only where it is free (stem, nn.Linear, weight-space products).
     precision: str = "bf16"
     # per-layer-class override {class: "exact" | "x3" | "16"} on top of ``precision`` (attribution runs only)
     override: Dict[str, str] = field(default_factory=dict)

@@ -26,6 +26,16 @@ __device__ __forceinline__ unsigned int gd_pack_bf2(float lo, float hi) {
     const gd_f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, gd_bf16x2_t));
 }
+// split-bf16 ("x3" operands, set_precision("mixed")): v = hi + lo with hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits.
+// Two values per dword like gd_pack_bf2.  A product of two split operands is hi*hi + lo*hi + hi*lo (+ 2^-16 relative).
+__device__ __forceinline__ void gd_split_bf2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    hi = gd_pack_bf2(a, b);
+    lo = gd_pack_bf2(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+__device__ __forceinline__ void gd_split_bf(float a, unsigned short& hi, unsigned short& lo) {
+    hi = gd_f2bf(a);
+    lo = gd_f2bf(a - gd_bf2f(hi));
+}
 // raw v_exp_f32 (2^x) without the denormal-range fix-up sequence exp2f() expands to; callers pass x <= ~0
 __device__ __forceinline__ float gd_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 

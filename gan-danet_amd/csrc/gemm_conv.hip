@@ -10,6 +10,8 @@
 // bit-exact f32 fma chain) share every line except the fragment code.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "tile_mma.h"
 #include "../../include/gandanet.h"
@@ -21,9 +23,11 @@ using gd::TILE_BN;
 constexpr int BN = TILE_BN;
 constexpr int BK = TILE_BK;
 
-template <int BM, bool BF16>
+template <int BM, int MODE>
 __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
-    using P = gd::TilePol<BF16>;
+    constexpr bool BF16 = MODE != gd::MODE_F32;     // 16-bit LDS images (one, or hi + lo for the split mode)
+    constexpr bool X3 = MODE == gd::MODE_X3;
+    using P = gd::TilePol<MODE>;
     using elem = typename P::elem;
     constexpr int LD = P::LD;
     constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
@@ -32,8 +36,8 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
     constexpr int KPT_A = BM / 8;   // A elements per thread per tile (BM*32/256)
     constexpr int KPT_B = 16;       // B elements per thread per tile (128*32/256)
 
-    __shared__ __attribute__((aligned(16))) elem As[BM * LD];
-    __shared__ __attribute__((aligned(16))) elem Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) elem As[P::PLANES * BM * LD];
+    __shared__ __attribute__((aligned(16))) elem Bs[P::PLANES * BN * LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -124,47 +128,52 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(const gd_conv_desc d) {
         }
     };
 
-    auto store_tile = [&]() {
-        if constexpr (BF16) {
-            // A: KPT_A consecutive k at row am
-            unsigned short* ap = As + am * LD + akg * KPT_A;
-            if constexpr (KPT_A >= 8) {
+    // `n` (a multiple of 4) consecutive k of one LDS row: 16-bit image (+ the lo image of the split mode) or plain f32
+    auto put_row = [&](elem* row, int plane_stride, const float* v, auto nc) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (BF16 && n % 8 == 0) {                // 16-byte LDS writes
 #pragma unroll
-                for (int i = 0; i < KPT_A; i += 8) {
-                    uint4 w;
-                    w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
-                    w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
-                    w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
-                    w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
-                    *reinterpret_cast<uint4*>(ap + i) = w;
+            for (int i = 0; i < n; i += 8) {
+                uint4 whi, wlo;
+                if constexpr (X3) {
+                    gd_split_bf2(v[i + 0], v[i + 1], whi.x, wlo.x);
+                    gd_split_bf2(v[i + 2], v[i + 3], whi.y, wlo.y);
+                    gd_split_bf2(v[i + 4], v[i + 5], whi.z, wlo.z);
+                    gd_split_bf2(v[i + 6], v[i + 7], whi.w, wlo.w);
+                    *reinterpret_cast<uint4*>(row + plane_stride + i) = wlo;
+                } else {
+                    whi.x = gd_pack_bf2(v[i + 0], v[i + 1]);
+                    whi.y = gd_pack_bf2(v[i + 2], v[i + 3]);
+                    whi.z = gd_pack_bf2(v[i + 4], v[i + 5]);
+                    whi.w = gd_pack_bf2(v[i + 6], v[i + 7]);
                 }
-            } else {  // KPT_A == 4
-                uint2 w;
-                w.x = gd_pack_bf2(ra[0], ra[1]);
-                w.y = gd_pack_bf2(ra[2], ra[3]);
-                *reinterpret_cast<uint2*>(ap) = w;
+                *reinterpret_cast<uint4*>(row + i) = whi;
             }
-            unsigned short* bp = Bs + bn * LD + bkh * KPT_B;
+        } else if constexpr (BF16) {
 #pragma unroll
-            for (int i = 0; i < KPT_B; i += 8) {
-                uint4 w;
-                w.x = gd_pack_bf2(rb[i + 0], rb[i + 1]);
-                w.y = gd_pack_bf2(rb[i + 2], rb[i + 3]);
-                w.z = gd_pack_bf2(rb[i + 4], rb[i + 5]);
-                w.w = gd_pack_bf2(rb[i + 6], rb[i + 7]);
-                *reinterpret_cast<uint4*>(bp + i) = w;
+            for (int i = 0; i < n; i += 4) {
+                uint2 whi, wlo;
+                if constexpr (X3) {
+                    gd_split_bf2(v[i + 0], v[i + 1], whi.x, wlo.x);
+                    gd_split_bf2(v[i + 2], v[i + 3], whi.y, wlo.y);
+                    *reinterpret_cast<uint2*>(row + plane_stride + i) = wlo;
+                } else {
+                    whi.x = gd_pack_bf2(v[i + 0], v[i + 1]);
+                    whi.y = gd_pack_bf2(v[i + 2], v[i + 3]);
+                }
+                *reinterpret_cast<uint2*>(row + i) = whi;
             }
         } else {
-            float* ap = As + am * LD + akg * KPT_A;
 #pragma unroll
-            for (int i = 0; i < KPT_A; ++i) ap[i] = ra[i];
-            float* bp = Bs + bn * LD + bkh * KPT_B;
-#pragma unroll
-            for (int i = 0; i < KPT_B; ++i) bp[i] = rb[i];
+            for (int i = 0; i < n; ++i) row[i] = v[i];
         }
     };
+    auto store_tile = [&]() {
+        put_row(As + am * LD + akg * KPT_A, BM * LD, ra, std::integral_constant<int, KPT_A>{});      // A: KPT_A consecutive k at row am
+        put_row(Bs + bn * LD + bkh * KPT_B, BN * LD, rb, std::integral_constant<int, KPT_B>{});
+    };
 
-    auto compute_tile = [&]() { gd::tile_mma<BM, BF16>(As, Bs, wm, wn, r, h, acc); };
+    auto compute_tile = [&]() { gd::tile_mma<BM, MODE>(As, Bs, wm, wn, r, h, acc); };
 
     // tiles whose tap cannot reach this output parity class are skipped (workgroup-uniform; strided data gradient)
     auto tile_live = [&](int t) -> bool {
@@ -255,15 +264,17 @@ constexpr int XLD = BN + 32;   // elements per staged channel row
 // SLOWER than NS = 1 (184 -> 230 projection: 3.1 / 3.6 / 3.6 ms; 184 -> 256 data gradient 1.7 / 2.2 / 3.0 ms): page
 // locality is not what holds this kernel back, occupancy (312 registers at NS = 4) costs more.  NS = 1 is the default;
 // the other instantiations stay behind GD_CONV1X1_NS for A/B runs.
-template <int BM, int NS>
+// X3: split-bf16 operands (hi and lo LDS images of both tiles, three MFMAs per product; gd::MODE_X3)
+template <int BM, int NS, bool X3 = false>
 __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
     constexpr int LDA = BK + 8;
+    constexpr int PL = X3 ? 2 : 1, A_PL = BM * LDA, X_PL = NS * BK * XLD;
     constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
     constexpr int TM = gd::TileGeom<BM>::TM;
     constexpr int TN = gd::TileGeom<BM>::TN;
     constexpr int KPT_A = BM / 8;
-    __shared__ __attribute__((aligned(16))) unsigned short As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[NS * BK * XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short As[PL * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[PL * X_PL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -340,56 +351,88 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
         if constexpr (KPT_A >= 8) {
 #pragma unroll
             for (int i = 0; i < KPT_A; i += 8) {
-                uint4 w;
-                w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
-                w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
-                w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
-                w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
-                *reinterpret_cast<uint4*>(ap + i) = w;
+                uint4 whi, wlo;
+                if constexpr (X3) {
+                    gd_split_bf2(ra[i + 0], ra[i + 1], whi.x, wlo.x);
+                    gd_split_bf2(ra[i + 2], ra[i + 3], whi.y, wlo.y);
+                    gd_split_bf2(ra[i + 4], ra[i + 5], whi.z, wlo.z);
+                    gd_split_bf2(ra[i + 6], ra[i + 7], whi.w, wlo.w);
+                    *reinterpret_cast<uint4*>(ap + A_PL + i) = wlo;
+                } else {
+                    whi.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
+                    whi.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
+                    whi.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
+                    whi.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
+                }
+                *reinterpret_cast<uint4*>(ap + i) = whi;
             }
         } else {
-            uint2 w;
-            w.x = gd_pack_bf2(ra[0], ra[1]);
-            w.y = gd_pack_bf2(ra[2], ra[3]);
-            *reinterpret_cast<uint2*>(ap) = w;
+            uint2 whi, wlo;
+            if constexpr (X3) {
+                gd_split_bf2(ra[0], ra[1], whi.x, wlo.x);
+                gd_split_bf2(ra[2], ra[3], whi.y, wlo.y);
+                *reinterpret_cast<uint2*>(ap + A_PL) = wlo;
+            } else {
+                whi.x = gd_pack_bf2(ra[0], ra[1]);
+                whi.y = gd_pack_bf2(ra[2], ra[3]);
+            }
+            *reinterpret_cast<uint2*>(ap) = whi;
         }
 #pragma unroll
         for (int sb = 0; sb < NS; ++sb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint2 w;
-                w.x = gd_pack_bf2(rx[sb][i].x, rx[sb][i].y);
-                w.y = gd_pack_bf2(rx[sb][i].z, rx[sb][i].w);
-                *reinterpret_cast<uint2*>(Xs + sb * (BK * XLD) + (xr0 + 8 * i) * XLD + xq * 4) = w;
+                uint2 whi, wlo;
+                unsigned short* xp = Xs + sb * (BK * XLD) + (xr0 + 8 * i) * XLD + xq * 4;
+                if constexpr (X3) {
+                    gd_split_bf2(rx[sb][i].x, rx[sb][i].y, whi.x, wlo.x);
+                    gd_split_bf2(rx[sb][i].z, rx[sb][i].w, whi.y, wlo.y);
+                    *reinterpret_cast<uint2*>(xp + X_PL) = wlo;
+                } else {
+                    whi.x = gd_pack_bf2(rx[sb][i].x, rx[sb][i].y);
+                    whi.y = gd_pack_bf2(rx[sb][i].z, rx[sb][i].w);
+                }
+                *reinterpret_cast<uint2*>(xp) = whi;
             }
     };
     // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
+    auto mma = [&](f32x16_t& c, const bf16x8_t& a, const bf16x8_t& bb) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gd::bf16x8_native_t, a),
+                                                    __builtin_bit_cast(gd::bf16x8_native_t, bb), c, 0, 0, 0);
+    };
     auto compute_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t fa[TM];
+            bf16x8_t fa[PL][TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[pl][i] = *reinterpret_cast<const bf16x8_t*>(As + pl * A_PL + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
 #pragma unroll
             for (int sb = 0; sb < NS; ++sb) {
-                bf16x8_t fb[TN];
+                bf16x8_t fb[PL][TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const unsigned short* p = Xs + sb * (BK * XLD) + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
-                    fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                }
+                for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned short* p = Xs + pl * X_PL + sb * (BK * XLD) + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                        fb[pl][j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[sb][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
-                            acc[sb][i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (X3) {
+                            mma(acc[sb][i][j], fa[1][i], fb[0][j]);
+                            mma(acc[sb][i][j], fa[0][i], fb[1][j]);
+                        }
+                        mma(acc[sb][i][j], fa[0][i], fb[0][j]);
+                    }
             }
         }
     };
@@ -443,7 +486,7 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
 
 static bool conv1x1_tr_eligible(const gd_conv_desc& d) {
     const long HW = (long)d.Ho * d.Wo;
-    return d.ks == 1 && d.stride == 1 && d.pad == 0 && d.precision == GD_PREC_BF16 && d.out_layout == 0 && !d.out_bf16 &&
+    return d.ks == 1 && d.stride == 1 && d.pad == 0 && (d.precision == GD_PREC_BF16 || d.precision == GD_PREC_X3) && d.out_layout == 0 && !d.out_bf16 &&
            (d.Mstore == 0 || d.Mstore == d.M) && d.Hi == d.Ho && d.Wi == d.Wo && HW % 4 == 0 && d.x_bs % 4 == 0 &&
            ((uintptr_t)d.x % 16) == 0;
 }
@@ -455,9 +498,11 @@ int launch(const gd_conv_desc& d, hipStream_t s) {
     if (hs <= 0 || ws <= 0) return 0;
     dim3 grid(gd_cdiv(hs * ws, BN), gd_cdiv(d.Mstore, BM), d.B);
     if (d.precision == GD_PREC_BF16)
-        hipLaunchKernelGGL((conv_nn_kernel<BM, true>), grid, dim3(256), 0, s, d);
+        hipLaunchKernelGGL((conv_nn_kernel<BM, gd::MODE_BF16>), grid, dim3(256), 0, s, d);
+    else if (d.precision == GD_PREC_X3)
+        hipLaunchKernelGGL((conv_nn_kernel<BM, gd::MODE_X3>), grid, dim3(256), 0, s, d);
     else
-        hipLaunchKernelGGL((conv_nn_kernel<BM, false>), grid, dim3(256), 0, s, d);
+        hipLaunchKernelGGL((conv_nn_kernel<BM, gd::MODE_F32>), grid, dim3(256), 0, s, d);
     GD_LAUNCH_CHECK();
     return 0;
 }
@@ -472,7 +517,7 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
     GD_CHECK_ARG(d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0, "gd_conv2d: bad spatial sizes");
     GD_CHECK_ARG(d.a && d.x && d.y, "gd_conv2d: null tensor");
     GD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr), "gd_conv2d: in_scale/in_shift must come together");
-    GD_CHECK_ARG(d.precision == GD_PREC_FP32 || d.precision == GD_PREC_BF16, "gd_conv2d: bad precision");
+    GD_CHECK_ARG(d.precision == GD_PREC_FP32 || d.precision == GD_PREC_BF16 || d.precision == GD_PREC_X3, "gd_conv2d: bad precision");
     GD_CHECK_ARG(d.out_layout == 0 || (d.out_layout == 1 && d.ldo >= d.Mstore), "gd_conv2d: bad output layout");
     GD_CHECK_ARG(!(d.out_bf16 && d.accumulate), "gd_conv2d: accumulate needs an fp32 output");
     GD_CHECK_ARG((long)d.Ho * d.Wo < (1L << 31) && d.B <= 65535, "gd_conv2d: image too large for one launch");
@@ -494,11 +539,16 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
         // long pixel runs per channel row (NS sub-tiles per workgroup) once the image is large enough to keep the chip full
         static const int ns_env = getenv("GD_CONV1X1_NS") ? atoi(getenv("GD_CONV1X1_NS")) : 1;   // measured: NS 2 / 4 are 20-50 % SLOWER (round 3)
         const long HWl = (long)d.Ho * d.Wo;
-        int ns = HWl * d.B >= (1L << 18) ? ns_env : 1;
+        int ns = (HWl * d.B >= (1L << 18) && d.precision == GD_PREC_BF16) ? ns_env : 1;
         if (bm == 128 && ns > 2) ns = 2;                  // 64 accumulator registers per sub-tile
         if (ns != 1 && ns != 2 && ns != 4) ns = 1;
         dim3 grid(gd_cdiv(HWl, BN * ns), gd_cdiv(d.M, bm), d.B);
 #define GD_C1X1(BM_, NS_) hipLaunchKernelGGL((conv1x1_tr_kernel<BM_, NS_>), grid, dim3(256), 0, s, d)
+        if (d.precision == GD_PREC_X3) {
+            if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_kernel<32, 1, true>), grid, dim3(256), 0, s, d);
+            else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_kernel<64, 1, true>), grid, dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((conv1x1_tr_kernel<128, 1, true>), grid, dim3(256), 0, s, d);
+        } else
         if (bm == 32) { if (ns == 4) GD_C1X1(32, 4); else if (ns == 2) GD_C1X1(32, 2); else GD_C1X1(32, 1); }
         else if (bm == 64) { if (ns == 4) GD_C1X1(64, 4); else if (ns == 2) GD_C1X1(64, 2); else GD_C1X1(64, 1); }
         else { if (ns == 2) GD_C1X1(128, 2); else GD_C1X1(128, 1); }

@@ -30,10 +30,13 @@ __global__ void fill_zero_kernel(float* c, long c_bs, long ldc, int B, int M, in
 
 // VEC: plain (non-im2col) operands whose rows, leading dimensions and segments are 16-byte friendly are staged
 // with float4 loads (4 consecutive k per thread) and 8-byte LDS writes instead of scalar loads / 2-byte writes.
-template <int BM, bool BF16, bool VEC = false>
+template <int BM, int MODE, bool VEC = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, int ktiles, int tiles_per_split,
                                                       int splits) {
-    using P = gd::TilePol<BF16>;
+    constexpr bool BF16 = MODE != gd::MODE_F32;     // 16-bit LDS images (one, or hi + lo for the split mode)
+    constexpr bool X3 = MODE == gd::MODE_X3;
+    constexpr int A_PL = BM * gd::TilePol<MODE>::LD, B_PL = gd::TILE_BN * gd::TilePol<MODE>::LD;
+    using P = gd::TilePol<MODE>;
     using elem = typename P::elem;
     constexpr int LD = P::LD;
     constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
@@ -42,8 +45,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
     constexpr int RA = BM / 8;   // A rows per thread per tile
     constexpr int RB = BN / 8;   // B rows per thread per tile (16)
 
-    __shared__ __attribute__((aligned(16))) elem As[BM * LD];
-    __shared__ __attribute__((aligned(16))) elem Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) elem As[P::PLANES * BM * LD];
+    __shared__ __attribute__((aligned(16))) elem Bs[P::PLANES * BN * LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -117,7 +120,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
     auto store_tile_vec = [&]() {
 #pragma unroll
         for (int i = 0; i < RAV; ++i) {
-            if constexpr (BF16) {
+            if constexpr (X3) {
+                uint2 whi, wlo;
+                gd_split_bf2(va[i].x, va[i].y, whi.x, wlo.x);
+                gd_split_bf2(va[i].z, va[i].w, whi.y, wlo.y);
+                *reinterpret_cast<uint2*>(As + (r0v + 32 * i) * LD + kq * 4) = whi;
+                *reinterpret_cast<uint2*>(As + A_PL + (r0v + 32 * i) * LD + kq * 4) = wlo;
+            } else if constexpr (BF16) {
                 uint2 w;
                 w.x = gd_pack_bf2(va[i].x, va[i].y);
                 w.y = gd_pack_bf2(va[i].z, va[i].w);
@@ -141,7 +150,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
                     }
                 }
             }
-            if constexpr (BF16) {
+            if constexpr (X3) {
+                uint2 whi, wlo;
+                gd_split_bf2(vb[i].x, vb[i].y, whi.x, wlo.x);
+                gd_split_bf2(vb[i].z, vb[i].w, whi.y, wlo.y);
+                *reinterpret_cast<uint2*>(Bs + (r0v + 32 * i) * LD + kq * 4) = whi;
+                *reinterpret_cast<uint2*>(Bs + B_PL + (r0v + 32 * i) * LD + kq * 4) = wlo;
+            } else if constexpr (BF16) {
                 uint2 w;
                 w.x = gd_pack_bf2(vb[i].x, vb[i].y);
                 w.y = gd_pack_bf2(vb[i].z, vb[i].w);
@@ -202,12 +217,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            if constexpr (BF16) As[(r0 + 8 * i) * LD + kk] = gd_f2bf(ra[i]);
+            if constexpr (X3) gd_split_bf(ra[i], As[(r0 + 8 * i) * LD + kk], As[A_PL + (r0 + 8 * i) * LD + kk]);
+            else if constexpr (BF16) As[(r0 + 8 * i) * LD + kk] = gd_f2bf(ra[i]);
             else As[(r0 + 8 * i) * LD + kk] = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if constexpr (BF16) Bs[(r0 + 8 * i) * LD + kk] = gd_f2bf(rb[i]);
+            if constexpr (X3) gd_split_bf(rb[i], Bs[(r0 + 8 * i) * LD + kk], Bs[B_PL + (r0 + 8 * i) * LD + kk]);
+            else if constexpr (BF16) Bs[(r0 + 8 * i) * LD + kk] = gd_f2bf(rb[i]);
             else Bs[(r0 + 8 * i) * LD + kk] = rb[i];
         }
     };
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const gd_gemm_nt_desc d, i
             if constexpr (VEC) load_tile_vec(t + 1);
             else load_tile(t + 1);
         }
-        gd::tile_mma<BM, BF16>(As, Bs, wm, wn, r, h, acc);
+        gd::tile_mma<BM, MODE>(As, Bs, wm, wn, r, h, acc);
         __syncthreads();
         if (t + 1 < t_end) {
             if constexpr (VEC) store_tile_vec();
@@ -277,11 +294,14 @@ int launch(const gd_gemm_nt_desc& d, int ktiles, int splits, hipStream_t s) {
                      d.a_ss % 4 == 0 && d.b_ss % 4 == 0 && d.a_bs % 4 == 0 && d.b_bs % 4 == 0 &&
                      ((uintptr_t)d.a % 16) == 0 && ((uintptr_t)d.bm % 16) == 0;
     if (d.precision == GD_PREC_BF16) {
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, true, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
-        else hipLaunchKernelGGL((gemm_nt_kernel<BM, true, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_BF16, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_BF16, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+    } else if (d.precision == GD_PREC_X3) {
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_X3, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_X3, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, false, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
-        else hipLaunchKernelGGL((gemm_nt_kernel<BM, false, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_F32, true>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
+        else hipLaunchKernelGGL((gemm_nt_kernel<BM, gd::MODE_F32, false>), grid, dim3(256), 0, s, d, ktiles, tps, splits);
     }
     GD_LAUNCH_CHECK();
     return 0;
@@ -296,7 +316,7 @@ extern "C" int gd_gemm_nt(const gd_gemm_nt_desc* dp, void* stream) {
     GD_CHECK_ARG(d.a && d.bm && d.c, "gd_gemm_nt: null tensor");
     GD_CHECK_ARG((long)d.kseg * d.klen < (1L << 31), "gd_gemm_nt: reduction too long");
     GD_CHECK_ARG((d.in_scale == nullptr) == (d.in_shift == nullptr), "gd_gemm_nt: in_scale/in_shift must come together");
-    GD_CHECK_ARG(d.precision == GD_PREC_FP32 || d.precision == GD_PREC_BF16, "gd_gemm_nt: bad precision");
+    GD_CHECK_ARG(d.precision == GD_PREC_FP32 || d.precision == GD_PREC_BF16 || d.precision == GD_PREC_X3, "gd_gemm_nt: bad precision");
     if (d.im2col) {
         GD_CHECK_ARG(d.ks > 0 && d.stride > 0 && d.pad >= 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0,
                      "gd_gemm_nt: bad im2col geometry");

@@ -14,14 +14,25 @@ namespace gd {
 constexpr int TILE_BN = 128;
 constexpr int TILE_BK = 32;
 
-template <bool BF16> struct TilePol;
-template <> struct TilePol<true> {
+// operand modes of the tile kernels (= GD_PREC_*): 0 exact f32, 1 bf16, 2 split-bf16 ("x3": every operand staged as a hi
+// and a lo bf16 image, three MFMAs per product: hi*hi + lo*hi + hi*lo, ~2^-16 relative, at a third of the bf16 rate
+// instead of the eighth of the f32 MFMA)
+constexpr int MODE_F32 = 0, MODE_BF16 = 1, MODE_X3 = 2;
+template <int MODE> struct TilePol;
+template <> struct TilePol<MODE_BF16> {
     using elem = unsigned short;
     static constexpr int LD = TILE_BK + 8;  // 40 bf16 = 80-byte rows: 16-B writes and reads conflict free
+    static constexpr int PLANES = 1;
 };
-template <> struct TilePol<false> {
+template <> struct TilePol<MODE_F32> {
     using elem = float;
     static constexpr int LD = TILE_BK + 1;  // 33 floats
+    static constexpr int PLANES = 1;
+};
+template <> struct TilePol<MODE_X3> {
+    using elem = unsigned short;
+    static constexpr int LD = TILE_BK + 8;
+    static constexpr int PLANES = 2;        // plane 0 hi, plane 1 lo (As + BM * LD, Bs + TILE_BN * LD)
 };
 
 template <int BM> struct TileGeom {
@@ -33,13 +44,39 @@ template <int BM> struct TileGeom {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_native_t;
 
-template <int BM, bool BF16>
-__device__ __forceinline__ void tile_mma(const typename TilePol<BF16>::elem* As, const typename TilePol<BF16>::elem* Bs,
+template <int BM, int MODE>
+__device__ __forceinline__ void tile_mma(const typename TilePol<MODE>::elem* As, const typename TilePol<MODE>::elem* Bs,
                                          int wm, int wn, int r, int h,
                                          f32x16_t (&acc)[TileGeom<BM>::TM][TileGeom<BM>::TN]) {
-    constexpr int LD = TilePol<BF16>::LD;
+    constexpr int LD = TilePol<MODE>::LD;
     constexpr int TM = TileGeom<BM>::TM, TN = TileGeom<BM>::TN;
-    if constexpr (BF16) {
+    if constexpr (MODE == MODE_X3) {
+#pragma unroll
+        for (int ks = 0; ks < TILE_BK / 16; ++ks) {
+            bf16x8_t fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[pl][i] = *reinterpret_cast<const bf16x8_t*>(As + pl * BM * LD + (wm * TM * 32 + i * 32 + r) * LD + ks * 16 + 8 * h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[pl][j] = *reinterpret_cast<const bf16x8_t*>(Bs + pl * TILE_BN * LD + (wn * TN * 32 + j * 32 + r) * LD + ks * 16 + 8 * h);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // the two small products first, the hi*hi product last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_native_t, fa[1][i]),
+                                                                       __builtin_bit_cast(bf16x8_native_t, fb[0][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_native_t, fa[0][i]),
+                                                                       __builtin_bit_cast(bf16x8_native_t, fb[1][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_native_t, fa[0][i]),
+                                                                       __builtin_bit_cast(bf16x8_native_t, fb[0][j]), acc[i][j], 0, 0, 0);
+                }
+        }
+    } else if constexpr (MODE == MODE_BF16) {
 #pragma unroll
         for (int ks = 0; ks < TILE_BK / 16; ++ks) {
             bf16x8_t fa[TM], fb[TN];

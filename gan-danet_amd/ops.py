@@ -23,8 +23,10 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_LEAKY
 
 
 def _prec(layer: str = "other") -> int:
-    """MFMA operand type of a layer class under the configured mode (config.sixteen_bit): 16-bit or exact f32"""
-    return L.PREC_BF16 if sixteen_bit(layer) else L.PREC_FP32
+    """MFMA operand type of a layer class under the configured mode (config.operand_mode): 16-bit, split-bf16 (the generic
+    conv / GEMM kernels split their fp32 operands while staging them) or exact f32"""
+    mode = operand_mode(layer)
+    return L.PREC_BF16 if mode == "16" else L.PREC_X3 if mode == "x3" else L.PREC_FP32
 
 
 def _x3(layer: str) -> bool:
@@ -344,7 +346,7 @@ class DenseBlockFn(Function):
                    and tuple(params[4].shape[2:]) == (3, 3))
         nhwc = DENSE_NHWC and prec == L.PREC_BF16 and aligned
         # "mixed": the same route on split-bf16 operands -- max(0, bn(x)) packed once as [hi | lo | hi] pixel-major
-        x3 = prec == L.PREC_FP32 and _x3("dense3x3") and aligned and C0 >= 32 and H * W * 3 * (C0 + nl * g) < (1 << 31)
+        x3 = prec == L.PREC_X3 and aligned and C0 >= 32 and H * W * 3 * (C0 + nl * g) < (1 << 31)
         packs: List[torch.Tensor] = []
         for l in range(nl):
             bw, bb, rm, rv, cw, cb = params[6 * l: 6 * l + 6]
@@ -802,6 +804,8 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, act: int):
         prec = _prec("disc")
+        if prec == L.PREC_X3:
+            prec = L.PREC_FP32     # weight-streaming skinny GEMMs (fc1: 8.6 GB per pass) are HBM-bound: exact costs nothing
         x = _c(x)
         Bn, Kin = x.shape
         Nout = w.shape[0]

@@ -38,7 +38,9 @@ int gd_sizeof_conv_desc(void);
 int gd_sizeof_gemm_nt_desc(void);
 
 enum { GD_PREC_FP32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32) */
-       GD_PREC_BF16 = 1  /* bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16) */ };
+       GD_PREC_BF16 = 1, /* bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16) */
+       GD_PREC_X3 = 2    /* split-bf16: fp32 operands staged as hi + lo bf16, hi*hi + lo*hi + hi*lo (~2^-16 relative):
+                            gd_conv2d and gd_gemm_nt only */ };
 enum { GD_ACT_NONE = 0, GD_ACT_RELU = 1, GD_ACT_LEAKY02 = 2, GD_ACT_SIGMOID = 3 };   /* sigmoid: gd_act_fwd/bwd only */
 
 /* ------------------------------------------------------------------------------------------

@@ -782,6 +782,59 @@ def test_conv3x3_split_bf16_vs_fp64(gd, case):
     assert relmax(yb, yr.float()) > 20 * relmax(y, yr.float())
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_generic_split_bf16_vs_fp64(gd, case):
+    """GD_PREC_X3 in the generic kernels (gd_conv2d: implicit-GEMM gather and the 1x1 transpose-read kernel; gd_gemm_nt:
+    the im2col / plain split-K weight gradients): fp32 operands split into hi + lo bf16 while they are staged, three MFMAs
+    per product.  Every generic conv shape of the net (1x1, stride 2, 4x4, Cin = 1 / 3, ragged) against torch in fp64 at
+    1e-4; LeakyReLU keeps the 3x3 / stride-1 cases off the pixel-major split route (ops._x3_eligible)."""
+    ops, _ = _ops()
+    B, Cin, H, W, Cout, k, s_, p_, bias = case
+    x = seeded((B, Cin, H, W), 81)
+    w = seeded((Cout, Cin, k, k), 82, 1.0 / math.sqrt(Cin * k * k))
+    b = seeded((Cout,), 83, 0.1) if bias else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, stride=s_, padding=p_), 0.2)
+    go = seeded(tuple(yr.shape), 84)
+    yr.backward(go.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if bias else None
+    with gd.precision("fp32"), gd.layer_override(other="x3"):
+        assert ops._prec("other") == ops.L.PREC_X3
+        y = ops.conv2d(xd, wd, bd, s_, p_, ops.ACT_LEAKY)
+        y.backward(go.to(DEV))
+    assert_close(y, yr.float(), 1e-4, "y")
+    assert_close(xd.grad, xr.grad.float(), 1e-4, "dx")
+    assert_close(wd.grad, wr.grad.float(), 1e-4, "dw")
+    if bias:
+        assert_close(bd.grad, br.grad.float(), 1e-5, "db")
+    xb = x.to(DEV)
+    with gd.precision("bf16"):
+        yb = ops.conv2d(xb, w.to(DEV), None if b is None else b.to(DEV), s_, p_, ops.ACT_LEAKY)
+    if Cin * k * k >= 64:        # plain bf16 operands are an order of magnitude further away once the reduction is long
+        assert relmax(yb, yr.float()) > 10 * relmax(y, yr.float())
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 200, 1, 4096, True), (3, 130, 70, 5, 333, False), (2, 24, 129, 2, 64, True)])
+def test_gemm_nt_split_bf16_vs_fp64(gd, shape):
+    """gd_gemm_nt with GD_PREC_X3 (float4-staged and scalar-staged variants, split-K atomics) against fp64"""
+    _, K = _ops()
+    Bn, M, N, kseg, klen, vec = shape
+    a = seeded((Bn, kseg, M, klen), 91)
+    bm = seeded((Bn, kseg, N, klen), 92)
+    ref = torch.einsum("bsmk,bsnk->bmn", a.double(), bm.double()).float()
+    c = torch.empty(Bn, M, N, device=DEV)
+    ad, bd = a.to(DEV), bm.to(DEV)
+    K.gemm_nt(B=Bn, M=M, N=N, kseg=kseg, klen=klen, a=ad, a_bs=kseg * M * klen, a_ss=M * klen, lda=klen, bm=bd,
+              b_bs=kseg * N * klen, b_ss=N * klen, ldb=klen, c=c, c_bs=M * N, ldc=N, precision=K.L.PREC_X3)
+    assert_close(c, ref, 1e-4, "split-bf16 NT GEMM")
+    cb = torch.empty_like(c)
+    K.gemm_nt(B=Bn, M=M, N=N, kseg=kseg, klen=klen, a=ad, a_bs=kseg * M * klen, a_ss=M * klen, lda=klen, bm=bd,
+              b_bs=kseg * N * klen, b_ss=N * klen, ldb=klen, c=cb, c_bs=M * N, ldc=N, precision=K.L.PREC_BF16)
+    assert relmax(cb, ref) > 10 * relmax(c, ref)
+
+
 def test_syncbn_kernels_merge_of_two_shards_equals_full_batch(gd):
     """SyncBN's kernels without torch.distributed: the (count, mean, M2) records of two unequal shards, stacked as the
     all-gather would deliver them, merge (gd_bn_stats_merge) to the statistics gd_bn_stats takes on the whole batch
