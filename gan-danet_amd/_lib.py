@@ -65,6 +65,7 @@ SIGNATURES = {
     "gd_conv3x3": (_i, [C.POINTER(ConvDesc), _p, _sz, _p]),
     "gd_conv3x3_wgrad": (_i, [_p, _l, _p, _p, _l, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "gd_pack_16_split": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _p, _l, _i, _l, _i, _i, _p, _l, _i, _l, _i, _i, _p]),
+    "gd_pack_16_split_masked": (_i, [_p, _l, _i, _i, _i, _p, _p, _i, _p, _l, _i, _l, _i, _i, _p, _l, _i, _l, _i, _i, _p, _l, _p]),
     "gd_split3_weights": (_i, [_p, _l, _l, _l, _p, _p]),
     "gd_bn_stats_ws_floats": (_sz, [_i, _i, _l]),
     "gd_bn_stats": (_i, [_p, _l, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
@@ -117,14 +118,14 @@ SIGNATURES = {
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "gd_conv3x3_nhwc_f32out": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p]),
-    "gd_disc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _f, _p, _p]),
-    "gd_disc_stem_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "gd_disc_stem_dgrad": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
-    "gd_conv3x3_nhwc_s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "gd_conv3x3_nhwc_s2_dgrad": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
-    "gd_nhwc_flatten_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
-    "gd_nhwc_flatten_bwd": (_i, [_p, _p, _f, _i, _i, _i, _p, _p]),
-    "gd_nhwc_to_nchw16": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "gd_disc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _f, _p, _i, _p]),
+    "gd_disc_stem_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
+    "gd_disc_stem_dgrad": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "gd_conv3x3_nhwc_s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "gd_conv3x3_nhwc_s2_dgrad": (_i, [_p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gd_nhwc_flatten_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p]),
+    "gd_nhwc_flatten_bwd": (_i, [_p, _p, _f, _i, _i, _i, _p, _i, _p]),
+    "gd_nhwc_to_nchw16": (_i, [_p, _i, _i, _i, _p, _p, _i, _p]),
     "gd_nhwc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "gd_nhwc_stem_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "gd_nhwc_maxpool2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),

@@ -271,6 +271,7 @@ struct NhwcConvArgs {
     long y32_bs;
     int H, W, Ho, Wo, K, M, act, tiles_x, nchunks;   // act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
     float slope;
+    int osplit;                   // 1: y holds 3 M channels per pixel, the result split as [hi | lo | hi] (operand mode "x3")
 };
 
 // S = stride (1: VGG stack; 2: the down-sampling convs of Discriminator1, discriminator.py:60-63 -- the patch of a
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
         for (int j = 0; j < TN; ++j) {
             const int oy = y0 + wn * TN + j;
             if (oy >= a.Ho) continue;
-            const long pbase = (((long)b * a.Ho + oy) * a.Wo + ox) * a.M;
+            const long pbase = (((long)b * a.Ho + oy) * a.Wo + ox) * (a.osplit ? 3 * a.M : a.M);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -438,8 +439,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
                         continue;
                     }
                     uint2 o;
-                    o.x = gd_pack_bf2(v[0], v[1]);
-                    o.y = gd_pack_bf2(v[2], v[3]);
+                    if (a.osplit) {
+                        uint2 lo;
+                        gd_split_bf2(v[0], v[1], o.x, lo.x);
+                        gd_split_bf2(v[2], v[3], o.y, lo.y);
+                        *reinterpret_cast<uint2*>(a.y + pbase + a.M + m) = lo;
+                        *reinterpret_cast<uint2*>(a.y + pbase + 2 * a.M + m) = o;
+                    } else {
+                        o.x = gd_pack_bf2(v[0], v[1]);
+                        o.y = gd_pack_bf2(v[2], v[3]);
+                    }
                     *reinterpret_cast<uint2*>(a.y + pbase + m) = o;
                 }
         }
@@ -462,6 +471,7 @@ struct NhwcDgrad2Args {
     unsigned short* dx;           // (B, H, W, K) bf16
     int H, W, Ho, Wo, K, M, tiles_x, nchunks;
     float slope;
+    int split;                    // 1: act and dx hold 3 K channels per pixel [hi | lo | hi] (dy / wp carry the split in M)
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_dgrad2_kernel(const NhwcDgrad2Args a) {
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_dgrad2_kernel(const NhwcD
         for (int j = 0; j < TN; ++j) {
             const int Y = 2 * (u0 + wn * TN + j) + py;
             if (Y >= a.H) continue;
-            const long pbase = (((long)b * a.H + Y) * a.W + X) * a.K;
+            const long pbase = (((long)b * a.H + Y) * a.W + X) * (a.split ? 3 * a.K : a.K);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m = mt * BM + wm * 32 + 8 * g + 4 * h;
@@ -596,8 +606,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_dgrad2_kernel(const NhwcD
                     if (!((mk.y >> 16) & 0x7FFFu) || (mk.y >> 31)) v[3] *= a.slope;
                 }
                 uint2 o;
-                o.x = gd_pack_bf2(v[0], v[1]);
-                o.y = gd_pack_bf2(v[2], v[3]);
+                if (a.split) {
+                    uint2 lo;
+                    gd_split_bf2(v[0], v[1], o.x, lo.x);
+                    gd_split_bf2(v[2], v[3], o.y, lo.y);
+                    *reinterpret_cast<uint2*>(a.dx + pbase + a.K + m) = lo;
+                    *reinterpret_cast<uint2*>(a.dx + pbase + 2 * a.K + m) = o;
+                } else {
+                    o.x = gd_pack_bf2(v[0], v[1]);
+                    o.y = gd_pack_bf2(v[2], v[3]);
+                }
                 *reinterpret_cast<uint2*>(a.dx + pbase + m) = o;
             }
         }
@@ -629,9 +647,9 @@ extern "C" int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int trans
 
 static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias, const void* mask, const void* res,
                             void* y, int B, int H, int W, int K, int M, int stride, int act, float slope, void* stream,
-                            float* y32 = nullptr, long y32_bs = 0) {
+                            float* y32 = nullptr, long y32_bs = 0, int osplit = 0) {
     NhwcConvArgs a;
-    a.y32 = y32; a.y32_bs = y32_bs;
+    a.y32 = y32; a.y32_bs = y32_bs; a.osplit = osplit;
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
     a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
     a.H = H; a.W = W; a.K = K; a.M = M; a.act = act; a.slope = slope;
@@ -679,25 +697,30 @@ extern "C" int gd_conv3x3_nhwc_f32out(const void* x, const void* wpack, const fl
 
 // stride 2 / pad 1 forward: x (B, H, W, K) bf16 -> y (B, (H-1)/2+1, (W-1)/2+1, M) bf16, + bias, act 0 none / 1 ReLU /
 // 2 LeakyReLU(slope).  wpack = gd_conv3x3_nhwc_pack(transposed = 0).
+// split = 1 (operand mode "x3"): x holds K = 3 Cin channels per pixel [hi | lo | hi], wpack comes from the weights split
+// [hi ; hi ; lo] along Cin (gd_split3_weights), and y receives 3 M channels per pixel, the result split the same way.
 extern "C" int gd_conv3x3_nhwc_s2(const void* x, const void* wpack, const float* bias, void* y, int B, int H, int W, int K,
-                                  int M, int act, float slope, void* stream) {
+                                  int M, int act, float slope, int split, void* stream) {
     GD_CHECK_ARG(x && wpack && y, "gd_conv3x3_nhwc_s2: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0 && act >= 0 && act <= 2,
                  "gd_conv3x3_nhwc_s2: channel counts must be multiples of 8, act in 0..2");
-    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc_s2: image too large");
-    return nhwc_conv_launch(x, wpack, bias, nullptr, nullptr, y, B, H, W, K, M, 2, act, slope, stream);
+    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M * (split ? 3 : 1) < (1L << 31), "gd_conv3x3_nhwc_s2: image too large");
+    return nhwc_conv_launch(x, wpack, bias, nullptr, nullptr, y, B, H, W, K, M, 2, act, slope, stream, nullptr, 0, split ? 1 : 0);
 }
 
 // data gradient of gd_conv3x3_nhwc_s2: dy (B, Ho, Wo, M) bf16 -> dx (B, H, W, K) bf16, optionally times
 // LeakyReLU'(act_out) with act_out (B, H, W, K) the activation output this conv consumed.
 // wpack_t = gd_conv3x3_nhwc_pack(transposed = 2).
+// split = 1: dy holds M = 3 Cout channels per pixel [hi | lo | hi], wpack_t comes from the weights split [hi ; hi ; lo] along
+// Cout, act_out and dx hold 3 K channels per pixel (the sign of a split value is the sign of its hi part).
 extern "C" int gd_conv3x3_nhwc_s2_dgrad(const void* dy, const void* wpack_t, const void* act_out, float slope, void* dx,
-                                        int B, int H, int W, int K, int M, void* stream) {
+                                        int B, int H, int W, int K, int M, int split, void* stream) {
     GD_CHECK_ARG(dy && wpack_t && dx, "gd_conv3x3_nhwc_s2_dgrad: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0,
                  "gd_conv3x3_nhwc_s2_dgrad: channel counts must be multiples of 8");
-    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc_s2_dgrad: image too large");
+    GD_CHECK_ARG((long)H * W * K * (split ? 3 : 1) < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc_s2_dgrad: image too large");
     NhwcDgrad2Args a;
+    a.split = split ? 1 : 0;
     a.dy = (const unsigned short*)dy; a.wp = (const unsigned short*)wpack_t; a.act = (const unsigned short*)act_out;
     a.dx = (unsigned short*)dx; a.H = H; a.W = W; a.K = K; a.M = M; a.slope = slope;
     a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;

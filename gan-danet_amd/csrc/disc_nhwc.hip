@@ -28,11 +28,37 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 // bf16 > 0  <=>  sign clear and magnitude non-zero
 __device__ __forceinline__ bool bf_pos(unsigned int h) { return (h & 0x7FFFu) && !(h & 0x8000u); }
 
+// Split activations (set_precision("mixed"), operand mode "x3"): a pixel's C logical channels are stored as the 3 C bf16
+// [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) -- the operand the pixel-major conv kernels take against weights
+// split [hi ; hi ; lo] along the contraction axis.  `row` = the pixel's first element, c8 = the channel octet.
+__device__ __forceinline__ void store8(unsigned short* row, int C, int c8, const float* v, int split) {
+    const u32x4_t hi = pack8(v);
+    *reinterpret_cast<u32x4_t*>(row + c8) = hi;
+    if (split) {
+        float r[8];
+        unpack8(hi, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = v[k] - r[k];
+        *reinterpret_cast<u32x4_t*>(row + C + c8) = pack8(r);
+        *reinterpret_cast<u32x4_t*>(row + 2 * C + c8) = hi;
+    }
+}
+__device__ __forceinline__ void load8(const unsigned short* row, int C, int c8, float* v, int split) {
+    unpack8(*reinterpret_cast<const u32x4_t*>(row + c8), v);
+    if (split) {
+        float l[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(row + C + c8), l);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += l[k];
+    }
+}
+
 // ---- stem forward: thread = (output pixel, output-channel octet); weights in LDS as [ci][tap][co] ---------------------
 __global__ __launch_bounds__(256) void disc_stem_fwd_kernel(const float* __restrict__ img, int Ci, int H, int W, int Ho, int Wo,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           int Co, float slope, unsigned short* __restrict__ y, long npix_total) {
+                                                           int Co, float slope, unsigned short* __restrict__ y, long npix_total, int split) {
     extern __shared__ float wl[];
+    const int RS = split ? 3 * Co : Co;                 // elements per output pixel
     for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
         const int co = i % Co, t = (i / Co) % 9, ci = i / (9 * Co);
         wl[i] = w[((long)co * Ci + ci) * 9 + t];
@@ -67,7 +93,7 @@ __global__ __launch_bounds__(256) void disc_stem_fwd_kernel(const float* __restr
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * slope;
-            *reinterpret_cast<u32x4_t*>(y + p * 64 + o8) = pack8(acc);
+            store8(y + p * RS, 64, o8, acc, split);
         }
         return;
     }
@@ -94,7 +120,7 @@ __global__ __launch_bounds__(256) void disc_stem_fwd_kernel(const float* __restr
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * slope;
-        *reinterpret_cast<u32x4_t*>(y + p * Co + o8) = pack8(acc);
+        store8(y + p * RS, Co, o8, acc, split);
     }
 }
 
@@ -104,8 +130,9 @@ __global__ __launch_bounds__(256) void disc_stem_fwd_kernel(const float* __restr
 // value and workgroup.  Requires Co == 64 (octet = tid & 7).
 __global__ __launch_bounds__(256) void disc_stem_wgrad_kernel(const unsigned short* __restrict__ g, const float* __restrict__ img,
                                                              int Ci, int H, int W, int Ho, int Wo, float* __restrict__ dw,
-                                                             float* __restrict__ db, long npix_total) {
+                                                             float* __restrict__ db, long npix_total, int split) {
     constexpr int Co = 64, OCT = 8;
+    const int RS = split ? 3 * Co : Co;
     __shared__ float red[4][OCT][80];
     const int ci = blockIdx.y;
     const long HW = (long)H * W, HWo = (long)Ho * Wo;
@@ -120,7 +147,7 @@ __global__ __launch_bounds__(256) void disc_stem_wgrad_kernel(const unsigned sho
         const int rem = (int)(p - b * HWo);
         const int py = rem / Wo, px = rem - py * Wo;
         float gv[8], xv[9];
-        unpack8(*reinterpret_cast<const u32x4_t*>(g + p * Co + o8), gv);
+        load8(g + p * RS, Co, o8, gv, split);
         const float* plane = img + (b * Ci + ci) * HW;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -162,8 +189,9 @@ __global__ __launch_bounds__(256) void disc_stem_wgrad_kernel(const unsigned sho
 constexpr int SD_T = 16, SD_HT = SD_T + 1, SD_NH = SD_HT * SD_HT;
 __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const unsigned short* __restrict__ g, int Ci, int H, int W, int Ho,
                                                              int Wo, const float* __restrict__ w, int Co,
-                                                             float* __restrict__ dimg, int tiles_x) {
+                                                             float* __restrict__ dimg, int tiles_x, int split) {
     extern __shared__ float smem[];
+    const int RS = split ? 3 * Co : Co;
     float* wl = smem;                                   // [ci][tap][co]
     float* T = smem + Ci * 9 * Co;                      // [ci*9 + tap][haloed gradient pixel]
     for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
@@ -183,10 +211,10 @@ __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const unsigned sho
 #pragma unroll
             for (int k = 0; k < 9; ++k) t[k] = 0.f;
             if (inside) {
-                const unsigned short* gp = g + (((long)b * Ho + qy) * Wo + qx) * Co;
+                const unsigned short* gp = g + (((long)b * Ho + qy) * Wo + qx) * RS;
                 for (int o8 = 0; o8 < Co; o8 += 8) {
                     float f[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(gp + o8), f);
+                    load8(gp, Co, o8, f, split);
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const float* wp = wl + (ci * 9 + k) * Co + o8;      // uniform address: LDS broadcast
@@ -226,15 +254,15 @@ __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const unsigned sho
 
 // ---- flatten: y (B, HW, C) bf16 -> f (B, C * HW) fp32, (c, h, w) order; lanes run along the pixel index ---------------
 __global__ __launch_bounds__(256) void flatten_fwd_kernel(const unsigned short* __restrict__ y, int HW, int C,
-                                                         float* __restrict__ f, long total) {
-    const int oct = C / 8;
+                                                         float* __restrict__ f, long total, int split) {
+    const int oct = C / 8, RS = split ? 3 * C : C;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int p = (int)(idx % HW);
         const long t = idx / HW;
         const int o8 = (int)(t % oct) * 8;
         const long b = t / oct;
         float v[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(y + (b * HW + p) * C + o8), v);
+        load8(y + (b * HW + p) * RS, C, o8, v, split);
         float* dst = f + (b * C + o8) * HW + p;
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[(long)k * HW] = v[k];
@@ -242,14 +270,15 @@ __global__ __launch_bounds__(256) void flatten_fwd_kernel(const unsigned short* 
 }
 // backward: g (B, HW, C) bf16 = df (B, C * HW) * LeakyReLU'(y)
 __global__ __launch_bounds__(256) void flatten_bwd_kernel(const float* __restrict__ df, const unsigned short* __restrict__ y,
-                                                         float slope, int HW, int C, unsigned short* __restrict__ g, long total) {
-    const int oct = C / 8;
+                                                         float slope, int HW, int C, unsigned short* __restrict__ g, long total,
+                                                         int split) {
+    const int oct = C / 8, RS = split ? 3 * C : C;      // the sign of a split value is the sign of its hi part
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int p = (int)(idx % HW);
         const long t = idx / HW;
         const int o8 = (int)(t % oct) * 8;
         const long b = t / oct;
-        const u32x4_t yv = *reinterpret_cast<const u32x4_t*>(y + (b * HW + p) * C + o8);
+        const u32x4_t yv = *reinterpret_cast<const u32x4_t*>(y + (b * HW + p) * RS + o8);
         const float* src = df + (b * C + o8) * HW + p;
         float v[8];
 #pragma unroll
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(256) void flatten_bwd_kernel(const float* __restric
             const unsigned int h = (k & 1) ? (yv[k >> 1] >> 16) : (yv[k >> 1] & 0xFFFFu);
             v[k] = src[(long)k * HW] * (bf_pos(h) ? 1.f : slope);
         }
-        *reinterpret_cast<u32x4_t*>(g + (b * HW + p) * C + o8) = pack8(v);
+        store8(g + (b * HW + p) * RS, C, o8, v, split);
     }
 }
 
@@ -266,7 +295,9 @@ __global__ __launch_bounds__(256) void flatten_bwd_kernel(const float* __restric
 // ([channel][pixel], rows padded to 72), the channel sums stay in registers until the end (one atomic per channel and
 // workgroup: per-tile atomics would pile millions of adds onto C addresses)
 constexpr int TT = 64, TLD = TT + 8;
-__global__ __launch_bounds__(256) void nhwc_to_nchw16_kernel(const unsigned short* __restrict__ g, int B, int HW, int C,
+// ldg = elements per pixel of g (C, or 3 C for a split gradient whose hi / lo parts are transposed by one launch each: g then
+// points at the part's first channel and the channel sums of the two launches add up to the sums of hi + lo)
+__global__ __launch_bounds__(256) void nhwc_to_nchw16_kernel(const unsigned short* __restrict__ g, int B, int HW, int C, int ldg,
                                                             unsigned short* __restrict__ gt, float* __restrict__ csum) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[TT * TLD];
     __shared__ float part[4][TT];
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw16_kernel(const unsigned shor
             const int it = tid + k * 256;
             const int pl = it >> 3, o8 = (it & 7) * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (p0 + pl < HW && c0 + o8 < C) v = *reinterpret_cast<const u32x4_t*>(g + (b * HW + p0 + pl) * C + c0 + o8);
+            if (p0 + pl < HW && c0 + o8 < C) v = *reinterpret_cast<const u32x4_t*>(g + (b * HW + p0 + pl) * ldg + c0 + o8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 tile[(o8 + 2 * j) * TLD + pl] = (unsigned short)(v[j] & 0xFFFFu);
@@ -336,19 +367,19 @@ static inline int grid_n(long n, int cap = 16384) {
 #define NS(s) ((hipStream_t)(s))
 
 extern "C" int gd_disc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co,
-                                float slope, void* y, void* stream) {
+                                float slope, void* y, int split, void* stream) {
     GD_CHECK_ARG(img && w && y && B > 0 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Ci * 9 * Co * 4 <= 65536,
                  "gd_disc_stem_fwd: needs Ci <= 4, Co % 8 == 0");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long npix = (long)B * Ho * Wo;
     hipLaunchKernelGGL(disc_stem_fwd_kernel, dim3(grid_n(npix * (Co / 8))), dim3(256), (size_t)Ci * 9 * Co * 4, NS(stream), img,
-                       Ci, H, W, Ho, Wo, w, bias, Co, slope, (unsigned short*)y, npix);
+                       Ci, H, W, Ho, Wo, w, bias, Co, slope, (unsigned short*)y, npix, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gd_disc_stem_wgrad(const void* g, const float* img, int B, int Ci, int H, int W, int Co, float* dw, float* db,
-                                  void* stream) {
+                                  int split, void* stream) {
     GD_CHECK_ARG(g && img && dw && B > 0 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co == 64,
                  "gd_disc_stem_wgrad: needs Ci <= 4, Co == 64");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -356,12 +387,13 @@ extern "C" int gd_disc_stem_wgrad(const void* g, const float* img, int B, int Ci
     GD_CHECK_ARG(hipMemsetAsync(dw, 0, (size_t)Co * Ci * 9 * sizeof(float), NS(stream)) == hipSuccess, "gd_disc_stem_wgrad: memset failed");
     if (db) GD_CHECK_ARG(hipMemsetAsync(db, 0, (size_t)Co * sizeof(float), NS(stream)) == hipSuccess, "gd_disc_stem_wgrad: memset failed");
     hipLaunchKernelGGL(disc_stem_wgrad_kernel, dim3(grid_n(npix * 8, 1024), Ci), dim3(256), 0, NS(stream), (const unsigned short*)g,
-                       img, Ci, H, W, Ho, Wo, dw, db, npix);
+                       img, Ci, H, W, Ho, Wo, dw, db, npix, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream) {
+extern "C" int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, int split,
+                                  void* stream) {
     GD_CHECK_ARG(g && w && dimg && B > 0 && B <= 65535 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0,
                  "gd_disc_stem_dgrad: needs Ci <= 4, Co % 8 == 0");
     const size_t lds = ((size_t)Ci * 9 * Co + (size_t)Ci * 9 * SD_NH) * sizeof(float);
@@ -370,29 +402,32 @@ extern "C" int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, co
     // tiles over the GRADIENT grid; a tile also writes the odd image row / column past its last gradient pixel
     const int tiles_x = (Wo + SD_T - 1) / SD_T, tiles_y = (Ho + SD_T - 1) / SD_T;
     hipLaunchKernelGGL(disc_stem_dgrad_kernel, dim3(tiles_x * tiles_y, B), dim3(256), lds, NS(stream), (const unsigned short*)g,
-                       Ci, H, W, Ho, Wo, w, Co, dimg, tiles_x);
+                       Ci, H, W, Ho, Wo, w, Co, dimg, tiles_x, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gd_nhwc_flatten_fwd(const void* y, int B, int HW, int C, float* f, void* stream) {
+extern "C" int gd_nhwc_flatten_fwd(const void* y, int B, int HW, int C, float* f, int split, void* stream) {
     GD_CHECK_ARG(y && f && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "gd_nhwc_flatten_fwd: C must be a multiple of 8");
     const long total = (long)B * HW * (C / 8);
-    hipLaunchKernelGGL(flatten_fwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)y, HW, C, f, total);
+    hipLaunchKernelGGL(flatten_fwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)y, HW, C, f, total, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gd_nhwc_flatten_bwd(const float* df, const void* y, float slope, int B, int HW, int C, void* g, void* stream) {
+extern "C" int gd_nhwc_flatten_bwd(const float* df, const void* y, float slope, int B, int HW, int C, void* g, int split,
+                                   void* stream) {
     GD_CHECK_ARG(df && y && g && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "gd_nhwc_flatten_bwd: C must be a multiple of 8");
     const long total = (long)B * HW * (C / 8);
     hipLaunchKernelGGL(flatten_bwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), df, (const unsigned short*)y, slope, HW,
-                       C, (unsigned short*)g, total);
+                       C, (unsigned short*)g, total, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum, void* stream) {
+// split = 1: g holds 3 C channels per pixel [hi | lo | hi]; gt receives TWO (B, C, HW) images, hi then lo (the dY operands of
+// the weight gradient's three accumulating launches), csum the sums of hi + lo
+extern "C" int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum, int split, void* stream) {
     GD_CHECK_ARG(g && gt && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "gd_nhwc_to_nchw16: C must be a multiple of 8");
     if (csum) GD_CHECK_ARG(hipMemsetAsync(csum, 0, (size_t)C * sizeof(float), NS(stream)) == hipSuccess, "gd_nhwc_to_nchw16: memset failed");
     const long ntiles = (long)B * ((HW + TT - 1) / TT);
@@ -401,7 +436,10 @@ extern "C" int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, 
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(nhwc_to_nchw16_kernel, dim3(cg, (unsigned)gy), dim3(256), 0, NS(stream), (const unsigned short*)g, B, HW, C,
-                       (unsigned short*)gt, csum);
+                       split ? 3 * C : C, (unsigned short*)gt, csum);
+    if (split)
+        hipLaunchKernelGGL(nhwc_to_nchw16_kernel, dim3(cg, (unsigned)gy), dim3(256), 0, NS(stream), (const unsigned short*)g + C, B, HW,
+                           C, 3 * C, (unsigned short*)gt + (long)B * C * HW, csum);
     GD_LAUNCH_CHECK();
     return 0;
 }

@@ -286,11 +286,13 @@ __global__ __launch_bounds__(256) void pack16_split_kernel(const float* __restri
                                                           const float* __restrict__ row_shift, int relu,
                                                           unsigned short* __restrict__ plain, long p_bs, int ldp, long p_cs,
                                                           int p_n, int p_pat, unsigned short* __restrict__ tr, long t_bs,
-                                                          int ldt, long t_cs, int t_n, int t_pat) {
+                                                          int ldt, long t_cs, int t_n, int t_pat,
+                                                          const float* __restrict__ mask, long m_bs) {
     constexpr int TLD = 72;
     __shared__ __attribute__((aligned(16))) unsigned short tile[2][64 * TLD];      // [0] hi, [1] lo
     const int b = blockIdx.z;
     const float* sp = s + (long)b * s_bs;
+    const float* mp = mask ? mask + (long)b * m_bs : nullptr;       // ReLU backward fused: v <- v where mask > 0, else 0
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     {
@@ -307,6 +309,10 @@ __global__ __launch_bounds__(256) void pack16_split_kernel(const float* __restri
                     v.x = fmaf(v.x, a, sh); v.y = fmaf(v.y, a, sh); v.z = fmaf(v.z, a, sh); v.w = fmaf(v.w, a, sh);
                 }
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (mp) {
+                    const float4 m = *reinterpret_cast<const float4*>(mp + (long)r * Cc + c);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
             }
             uint2 hi;
             hi.x = gd_pack_bf2(v.x, v.y);
@@ -873,9 +879,12 @@ extern "C" int gd_pack_16_affine(const float* s, long s_bs, int B, int R, int Cc
 // split-bf16 pack (see pack16_split_kernel).  plain: copies of the (R, Cc) tile as rows of length ldp (channel-major),
 // tr: copies of its transpose as rows of length ldt (pixel-major); image b of copy j at ptr + j * cs + b * bs; copy j
 // holds the lo part when bit j of the pattern is set, else the hi part.  Pad columns beyond the data are NOT written.
-extern "C" int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
-                                int relu, void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr,
-                                long t_bs, int ldt, long t_cs, int t_ncopy, int t_pattern, void* stream) {
+// mask (optional, (B, R, Cc) fp32 with batch stride m_bs): the ReLU backward fused into the pack -- elements whose mask value is
+// not positive are packed as zero (dY of a conv whose output went through ReLU, masked by that output)
+extern "C" int gd_pack_16_split_masked(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
+                                       int relu, void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr,
+                                       long t_bs, int ldt, long t_cs, int t_ncopy, int t_pattern, const float* mask, long m_bs,
+                                       void* stream) {
     GD_CHECK_ARG(s && (plain || tr) && B > 0 && B <= 65535 && R > 0 && Cc > 0, "gd_pack_16_split: bad arguments");
     GD_CHECK_ARG((row_scale == nullptr) == (row_shift == nullptr), "gd_pack_16_split: row_scale / row_shift come together");
     GD_CHECK_ARG(Cc % 8 == 0 && R % 8 == 0 && s_bs % 4 == 0 && ((uintptr_t)s % 16) == 0, "gd_pack_16_split: R, Cc must be multiples of 8");
@@ -884,11 +893,18 @@ extern "C" int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc,
     GD_CHECK_ARG(!tr || (ldt >= R && ldt % 8 == 0 && t_ncopy >= 1 && t_ncopy <= 3 && t_cs % 8 == 0 && t_bs % 8 == 0 && (uintptr_t)tr % 16 == 0),
                  "gd_pack_16_split: transposed output needs ldt >= R, ldt % 8 == 0, 1..3 copies, 16-byte aligned strides");
     GD_CHECK_ARG(gd_cdiv(R, 64) <= 65535, "gd_pack_16_split: too many rows");
+    GD_CHECK_ARG(!mask || (m_bs % 4 == 0 && ((uintptr_t)mask % 16) == 0), "gd_pack_16_split: mask must be 16-byte aligned");
     hipLaunchKernelGGL(pack16_split_kernel, dim3(gd_cdiv(Cc, 64), gd_cdiv(R, 64), B), dim3(256), 0, GD_S, s, s_bs, R, Cc, row_scale,
                        row_shift, relu, (unsigned short*)plain, p_bs, ldp, p_cs, p_ncopy, p_pattern, (unsigned short*)tr, t_bs, ldt,
-                       t_cs, t_ncopy, t_pattern);
+                       t_cs, t_ncopy, t_pattern, mask, m_bs);
     GD_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
+                                int relu, void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr,
+                                long t_bs, int ldt, long t_cs, int t_ncopy, int t_pattern, void* stream) {
+    return gd_pack_16_split_masked(s, s_bs, B, R, Cc, row_scale, row_shift, relu, plain, p_bs, ldp, p_cs, p_ncopy, p_pattern, tr,
+                                   t_bs, ldt, t_cs, t_ncopy, t_pattern, nullptr, 0, stream);
 }
 extern "C" int gd_split3_weights(const float* w, long A, long Bn, long Cn, float* out, void* stream) {
     GD_CHECK_ARG(w && out && A > 0 && Bn > 0 && Cn > 0, "gd_split3_weights: bad arguments");

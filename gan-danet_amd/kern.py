@@ -943,18 +943,23 @@ HLH, HL, H_ONLY = 0b010, 0b10, 0b0      # copy patterns of pack_split: bit j set
 
 
 def pack_split(x: Tensor, *, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, relu: bool = False,
-               want_plain: bool = False, want_tr: bool = True):
+               want_plain: bool = False, want_tr: bool = True, mask: Optional[Tensor] = None):
     """(B, C, H, W) / (B, C, N) fp32 (per-image dense) -> split-bf16 copies (gd_pack_16_split):
     tr    (B, N, 3 C) pixel-major [hi | lo | hi]: the forward / data-gradient operand against gd_split3_weights
-    plain (2, B, C, N) channel-major, [0] hi and [1] lo: the dY operand of the weight gradient's three launches"""
+    plain (2, B, C, N) channel-major, [0] hi and [1] lo: the dY operand of the weight gradient's three launches
+    mask: a ReLU output of x's shape -- the ReLU backward fused into the pack (x packed as zero where mask <= 0)"""
     sbs = _bview(x, "pack input")
+    if mask is not None and tuple(mask.shape[:2]) + (mask[0, 0].numel(),) != tuple(x.shape[:2]) + (x[0, 0].numel(),):
+        raise L.GandanetError(f"pack_split: mask {tuple(mask.shape)} does not match {tuple(x.shape)}")
     B, Cn = x.shape[0], x.shape[1]
     N = x[0, 0].numel()
     plain = torch.empty(2, B, Cn, N, device=x.device, dtype=torch.bfloat16) if want_plain else None
     tr = torch.empty(B, N, 3 * Cn, device=x.device, dtype=torch.bfloat16) if want_tr else None
-    L.check(lib().gd_pack_16_split(_ptr(x), sbs, B, Cn, N, _ptr(scale), _ptr(shift), int(relu),
-                                   _ptr(plain), Cn * N, N, B * Cn * N, 2, HL,
-                                   _ptr(tr), N * 3 * Cn, 3 * Cn, Cn, 3, HLH, _stream()), "gd_pack_16_split")
+    L.check(lib().gd_pack_16_split_masked(_ptr(x), sbs, B, Cn, N, _ptr(scale), _ptr(shift), int(relu),
+                                          _ptr(plain), Cn * N, N, B * Cn * N, 2, HL,
+                                          _ptr(tr), N * 3 * Cn, 3 * Cn, Cn, 3, HLH,
+                                          _ptr(mask), 0 if mask is None else _bview(mask, "pack mask"), _stream()),
+            "gd_pack_16_split")
     return plain, tr
 
 
@@ -993,104 +998,126 @@ def _half_up(n: int) -> int:
     return (n - 1) // 2 + 1
 
 
-def disc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], slope: float) -> Tensor:
-    """conv1: fp32 NCHW image -> LeakyReLU(conv3x3 s2 p1 + bias) as (B, Ho, Wo, Co) bf16"""
+def disc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], slope: float, split: bool = False) -> Tensor:
+    """conv1: fp32 NCHW image -> LeakyReLU(conv3x3 s2 p1 + bias) as (B, Ho, Wo, Co) bf16; ``split`` (here and in the
+    functions below): pixel-major tensors carry 3 C channels per pixel, the values split [hi | lo | hi] (operand mode "x3")"""
     _dense(img, "stem image"), _dense(w, "stem weight")
     B, Ci, H, W = img.shape
     Co = w.shape[0]
     if w.shape[1] != Ci:
         raise L.GandanetError(f"disc_stem_fwd: weight {tuple(w.shape)} does not match image {tuple(img.shape)}")
-    y = torch.empty(B, _half_up(H), _half_up(W), Co, device=img.device, dtype=torch.bfloat16)
-    L.check(lib().gd_disc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, float(slope), _ptr(y), _stream()),
+    y = torch.empty(B, _half_up(H), _half_up(W), (3 if split else 1) * Co, device=img.device, dtype=torch.bfloat16)
+    L.check(lib().gd_disc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, float(slope), _ptr(y), int(split), _stream()),
             "gd_disc_stem_fwd")
     return y
 
 
-def disc_stem_wgrad(g: Tensor, img: Tensor, want_bias: bool = True):
+def disc_stem_wgrad(g: Tensor, img: Tensor, want_bias: bool = True, split: bool = False):
     """(dw (Co, Ci, 3, 3), db (Co) or None) of conv1 from the pre-activation gradient g (B, Ho, Wo, Co) bf16"""
     _bf(g, "stem gradient"), _dense(img, "stem image")
     B, Ci, H, W = img.shape
-    Co = g.shape[3]
+    Co = g.shape[3] // (3 if split else 1)
     if g.shape[:3] != (B, _half_up(H), _half_up(W)):
         raise L.GandanetError(f"disc_stem_wgrad: gradient {tuple(g.shape)} does not match image {tuple(img.shape)}")
     dw = torch.empty(Co, Ci, 3, 3, device=g.device, dtype=torch.float32)
     db = torch.empty(Co, device=g.device, dtype=torch.float32) if want_bias else None
-    L.check(lib().gd_disc_stem_wgrad(_ptr(g), _ptr(img), B, Ci, H, W, Co, _ptr(dw), _ptr(db), _stream()), "gd_disc_stem_wgrad")
+    L.check(lib().gd_disc_stem_wgrad(_ptr(g), _ptr(img), B, Ci, H, W, Co, _ptr(dw), _ptr(db), int(split), _stream()),
+            "gd_disc_stem_wgrad")
     return dw, db
 
 
-def disc_stem_dgrad(g: Tensor, w: Tensor, H: int, W: int) -> Tensor:
+def disc_stem_dgrad(g: Tensor, w: Tensor, H: int, W: int, split: bool = False) -> Tensor:
     _bf(g, "stem gradient"), _dense(w, "stem weight")
     B, Ho, Wo, Co = g.shape
+    Co //= 3 if split else 1
     Ci = w.shape[1]
     if (Ho, Wo) != (_half_up(H), _half_up(W)):
         raise L.GandanetError(f"disc_stem_dgrad: gradient {tuple(g.shape)} does not match a {H} x {W} image")
     dimg = torch.empty(B, Ci, H, W, device=g.device, dtype=torch.float32)
-    L.check(lib().gd_disc_stem_dgrad(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), _stream()), "gd_disc_stem_dgrad")
+    L.check(lib().gd_disc_stem_dgrad(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), int(split), _stream()), "gd_disc_stem_dgrad")
     return dimg
 
 
-def conv3x3_nhwc_s2(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, act: int, slope: float = 0.2) -> Tensor:
-    """x (B, H, W, K) bf16 -> act(conv3x3 s2 p1 + bias) (B, Ho, Wo, M) bf16; act 0 none / 1 ReLU / 2 LeakyReLU(slope)"""
+def conv3x3_nhwc_s2(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, act: int, slope: float = 0.2,
+                    split: bool = False) -> Tensor:
+    """x (B, H, W, K) bf16 -> act(conv3x3 s2 p1 + bias) (B, Ho, Wo, M) bf16; act 0 none / 1 ReLU / 2 LeakyReLU(slope);
+    split: K = 3 Cin physical channels in, 3 M out, wpack from split3_weights(w, 1)"""
     _bf(x, "nhwc conv input")
     B, H, W, Kc = x.shape
-    y = torch.empty(B, _half_up(H), _half_up(W), M, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(B, _half_up(H), _half_up(W), (3 if split else 1) * M, device=x.device, dtype=torch.bfloat16)
     with _Bracket("conv3x3_nhwc_s2", 2.0 * 9 * Kc * M * y.shape[1] * y.shape[2] * B):
         L.check(lib().gd_conv3x3_nhwc_s2(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(y), B, H, W, Kc, M, int(act), float(slope),
-                                         _stream()), "gd_conv3x3_nhwc_s2")
+                                         int(split), _stream()), "gd_conv3x3_nhwc_s2")
     return y
 
 
-def conv3x3_nhwc_s2_dgrad(dy: Tensor, wpack_t: Tensor, act_out: Tensor, slope: float = 0.2) -> Tensor:
-    """dy (B, Ho, Wo, M) bf16 -> dx (B, H, W, K) bf16 = convT(dy) * LeakyReLU'(act_out); shape taken from act_out"""
+def conv3x3_nhwc_s2_dgrad(dy: Tensor, wpack_t: Tensor, act_out: Tensor, slope: float = 0.2, split: bool = False) -> Tensor:
+    """dy (B, Ho, Wo, M) bf16 -> dx (B, H, W, K) bf16 = convT(dy) * LeakyReLU'(act_out); shape taken from act_out;
+    split: dy carries M = 3 Cout physical channels, act_out and dx 3 K, wpack_t from split3_weights(w, 0)"""
     _bf(dy, "nhwc conv gradient"), _bf(act_out, "activation output")
     B, H, W, Kc = act_out.shape
+    Kc //= 3 if split else 1
     M = dy.shape[3]
     if dy.shape[:3] != (B, _half_up(H), _half_up(W)):
         raise L.GandanetError(f"conv3x3_nhwc_s2_dgrad: dy {tuple(dy.shape)} does not match input {tuple(act_out.shape)}")
     dx = torch.empty_like(act_out)
     with _Bracket("conv3x3_nhwc_s2_dgrad", 2.0 * 9 * Kc * M * dy.shape[1] * dy.shape[2] * B):
         L.check(lib().gd_conv3x3_nhwc_s2_dgrad(_ptr(dy), _ptr(wpack_t), _ptr(act_out), float(slope), _ptr(dx), B, H, W, Kc, M,
-                                               _stream()), "gd_conv3x3_nhwc_s2_dgrad")
+                                               int(split), _stream()), "gd_conv3x3_nhwc_s2_dgrad")
     return dx
 
 
-def nhwc_flatten_fwd(y: Tensor) -> Tensor:
+def nhwc_flatten_fwd(y: Tensor, split: bool = False) -> Tensor:
     """(B, h, w, C) bf16 -> (B, C*h*w) fp32 in the (c, h, w) order of NCHW .flatten(1)"""
     _bf(y, "flatten input")
     B, H, W, Cc = y.shape
+    Cc //= 3 if split else 1
     f = torch.empty(B, Cc * H * W, device=y.device, dtype=torch.float32)
-    L.check(lib().gd_nhwc_flatten_fwd(_ptr(y), B, H * W, Cc, _ptr(f), _stream()), "gd_nhwc_flatten_fwd")
+    L.check(lib().gd_nhwc_flatten_fwd(_ptr(y), B, H * W, Cc, _ptr(f), int(split), _stream()), "gd_nhwc_flatten_fwd")
     return f
 
 
-def nhwc_flatten_bwd(df: Tensor, y: Tensor, slope: float) -> Tensor:
+def nhwc_flatten_bwd(df: Tensor, y: Tensor, slope: float, split: bool = False) -> Tensor:
     _bf(y, "flatten input"), _dense(df, "flatten gradient")
     B, H, W, Cc = y.shape
-    if df.numel() != y.numel():
+    Cc //= 3 if split else 1
+    if df.numel() * (3 if split else 1) != y.numel():
         raise L.GandanetError(f"nhwc_flatten_bwd: gradient {tuple(df.shape)} does not match {tuple(y.shape)}")
     g = torch.empty_like(y)
-    L.check(lib().gd_nhwc_flatten_bwd(_ptr(df), _ptr(y), float(slope), B, H * W, Cc, _ptr(g), _stream()), "gd_nhwc_flatten_bwd")
+    L.check(lib().gd_nhwc_flatten_bwd(_ptr(df), _ptr(y), float(slope), B, H * W, Cc, _ptr(g), int(split), _stream()),
+            "gd_nhwc_flatten_bwd")
     return g
 
 
-def nhwc_to_nchw16(g: Tensor, want_sum: bool):
-    """(B, h, w, C) bf16 -> ((B, C, h, w) bf16, per-channel sums (C) fp32 or None)"""
+def nhwc_to_nchw16(g: Tensor, want_sum: bool, split: bool = False):
+    """(B, h, w, C) bf16 -> ((B, C, h, w) bf16, per-channel sums (C) fp32 or None); split: g carries 3 C channels
+    [hi | lo | hi] and the result is (2, B, C, h, w), hi then lo, with the sums of hi + lo"""
     _bf(g, "nhwc gradient")
     B, H, W, Cc = g.shape
-    gt = torch.empty(B, Cc, H, W, device=g.device, dtype=torch.bfloat16)
+    Cc //= 3 if split else 1
+    gt = torch.empty((2, B, Cc, H, W) if split else (B, Cc, H, W), device=g.device, dtype=torch.bfloat16)
     cs = torch.empty(Cc, device=g.device, dtype=torch.float32) if want_sum else None
-    L.check(lib().gd_nhwc_to_nchw16(_ptr(g), B, H * W, Cc, _ptr(gt), _ptr(cs), _stream()), "gd_nhwc_to_nchw16")
+    L.check(lib().gd_nhwc_to_nchw16(_ptr(g), B, H * W, Cc, _ptr(gt), _ptr(cs), int(split), _stream()), "gd_nhwc_to_nchw16")
     return gt, cs
 
 
-def conv3x3_wgrad_nhwc(g: Tensor, x: Tensor, stride: int, want_bias: bool):
+def conv3x3_wgrad_nhwc(g: Tensor, x: Tensor, stride: int, want_bias: bool, split: bool = False):
     """Weight (and bias) gradient of a 3x3 / pad 1 conv whose input x (B, H, W, Cin) and output gradient g
-    (B, Ho, Wo, Cout) are pixel-major bf16: g goes channel-major once (fused with the bias sums), x is staged as is."""
+    (B, Ho, Wo, Cout) are pixel-major bf16: g goes channel-major once (fused with the bias sums), x is staged as is.
+    split: both carry [hi | lo | hi]; dW = g_hi (x) x_hi + g_lo (x) x_hi + g_hi (x) x_lo in three accumulating launches."""
     _bf(g, "nhwc gradient"), _bf(x, "nhwc input")
     B, H, W, Cin = x.shape
     Cout = g.shape[3]
-    gt, db = nhwc_to_nchw16(g, want_bias)
+    gt, db = nhwc_to_nchw16(g, want_bias, split)
+    if split:
+        Cin //= 3
+        Cout //= 3
+        dw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
+        with _ConvBracket("wgrad_nhwc_x3", 3, stride, Cin, Cout, g.shape[1], g.shape[2], B):
+            for j, (dpart, xoff) in enumerate(((0, 0), (1, 0), (0, Cin))):
+                L.check(lib().gd_conv3x3_wgrad(None, 0, gt[dpart].data_ptr(), None, 0, x.data_ptr() + 2 * xoff, 3 * Cin, None, None,
+                                               0, B, Cout, Cin, H, W, stride, int(j > 0), _ptr(dw), _stream()), "gd_conv3x3_wgrad")
+        return dw, db
     dw = torch.empty(Cout, Cin, 3, 3, device=g.device, dtype=torch.float32)
     with _ConvBracket("wgrad_nhwc", 3, stride, Cin, Cout, g.shape[1], g.shape[2], B):
         L.check(lib().gd_conv3x3_wgrad(None, 0, _ptr(gt), None, 0, _ptr(x), Cin, None, None, 0, B, Cout, Cin, H, W, stride,

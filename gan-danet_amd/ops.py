@@ -59,9 +59,9 @@ DISC_NHWC = os.environ.get("GD_DISC_NHWC", "1") != "0"
 
 
 def disc1_trunk_eligible(x: torch.Tensor, ws) -> bool:
-    """16-bit operand mode, non-deterministic mode (the bias sums and weight gradients use atomics), the reference's
-    channel ladder (.. -> 64 -> .. multiples of 8), at most 4 image channels"""
-    return (DISC_NHWC and sixteen_bit("disc") and not K.DETERMINISTIC and x.dim() == 4 and x.shape[1] <= 4
+    """16-bit or split-bf16 operand mode, non-deterministic mode (the bias sums and weight gradients use atomics), the
+    reference's channel ladder (.. -> 64 -> .. multiples of 8), at most 4 image channels"""
+    return (DISC_NHWC and (sixteen_bit("disc") or _x3("disc")) and not K.DETERMINISTIC and x.dim() == 4 and x.shape[1] <= 4
             and ws[0].shape[0] == 64 and all(w.shape[0] % 8 == 0 and w.shape[2:] == (3, 3) for w in ws))
 
 
@@ -76,31 +76,38 @@ class Disc1TrunkFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4):
         x = _c(x)
+        # operand mode "x3" (set_precision("mixed")): the same node on SPLIT activations -- every pixel-major tensor holds
+        # [hi | lo | hi] (3 C bf16 channels per pixel) against weights split [hi ; hi ; lo] along the contraction axis
+        sp = _x3("disc")
         ws, bs = (w1, w2, w3, w4), (b1, b2, b3, b4)
-        acts = [K.disc_stem_fwd(x, _c(w1), b1, Disc1TrunkFn.SLOPE)]
+        acts = [K.disc_stem_fwd(x, _c(w1), b1, Disc1TrunkFn.SLOPE, split=sp)]
         for w, b in zip(ws[1:], bs[1:]):
-            acts.append(K.conv3x3_nhwc_s2(acts[-1], K.conv3x3_nhwc_pack(_c(w), 0), b, w.shape[0], 2, Disc1TrunkFn.SLOPE))
+            wp = K.conv3x3_nhwc_pack(K.split3_weights(_c(w), 1) if sp else _c(w), 0)
+            acts.append(K.conv3x3_nhwc_s2(acts[-1], wp, b, w.shape[0], 2, Disc1TrunkFn.SLOPE, split=sp))
         ctx.save_for_backward(x, *ws, *acts)       # autograd's version check guards x / the weights against in-place edits
         ctx.has_bias = tuple(b is not None for b in bs)
-        return K.nhwc_flatten_fwd(acts[-1])
+        ctx.split = sp
+        return K.nhwc_flatten_fwd(acts[-1], split=sp)
 
     @staticmethod
     def backward(ctx, df):
         x, *rest = ctx.saved_tensors
         ws, acts = rest[:4], rest[4:]
         need = ctx.needs_input_grad
+        sp = ctx.split
         grads = [None] * 9
-        g = K.nhwc_flatten_bwd(_c(df), acts[3], Disc1TrunkFn.SLOPE)          # w.r.t. conv4's pre-activation
+        g = K.nhwc_flatten_bwd(_c(df), acts[3], Disc1TrunkFn.SLOPE, split=sp)          # w.r.t. conv4's pre-activation
         for l in (3, 2, 1):
             if need[1 + 2 * l] or need[2 + 2 * l]:
-                dw, db = K.conv3x3_wgrad_nhwc(g, acts[l - 1], 2, ctx.has_bias[l] and need[2 + 2 * l])
+                dw, db = K.conv3x3_wgrad_nhwc(g, acts[l - 1], 2, ctx.has_bias[l] and need[2 + 2 * l], split=sp)
                 grads[1 + 2 * l], grads[2 + 2 * l] = (dw if need[1 + 2 * l] else None), db
-            g = K.conv3x3_nhwc_s2_dgrad(g, K.conv3x3_nhwc_pack(_c(ws[l]), 2), acts[l - 1], Disc1TrunkFn.SLOPE)
+            wp = K.conv3x3_nhwc_pack(K.split3_weights(_c(ws[l]), 0) if sp else _c(ws[l]), 2)
+            g = K.conv3x3_nhwc_s2_dgrad(g, wp, acts[l - 1], Disc1TrunkFn.SLOPE, split=sp)
         if need[1] or need[2]:
-            dw, db = K.disc_stem_wgrad(g, x, ctx.has_bias[0] and need[2])
+            dw, db = K.disc_stem_wgrad(g, x, ctx.has_bias[0] and need[2], split=sp)
             grads[1], grads[2] = (dw if need[1] else None), db
         if need[0]:
-            grads[0] = K.disc_stem_dgrad(g, _c(ws[0]), x.shape[2], x.shape[3])
+            grads[0] = K.disc_stem_dgrad(g, _c(ws[0]), x.shape[2], x.shape[3], split=sp)
         return tuple(grads)
 
 
@@ -158,13 +165,17 @@ class Conv2dFn(Function):
         x, w, y = ctx.saved_tensors
         stride, pad, act, prec, has_bias = ctx.cfg
         dy = _c(dy)
-        if act != ACT_NONE:
+        # split route with frozen weights (the VGG stack of PerceptualLoss): the ReLU backward rides in the pack of dY
+        fuse_mask = (ctx.wide is not None and ctx.wide[2] and act == ACT_RELU and not ctx.needs_input_grad[1]
+                     and not (has_bias and ctx.needs_input_grad[2]))
+        if act != ACT_NONE and not fuse_mask:
             dy = K.act_bwd(y, dy, act)
         dx = dw = db = None
         if ctx.wide is not None and ctx.wide[2]:
             H, W, _ = ctx.wide
             B, Cout = dy.shape[0], dy.shape[1]
-            dy2, dyt = K.pack_split(dy.view(B, Cout, H * W), want_plain=ctx.needs_input_grad[1], want_tr=ctx.needs_input_grad[0])
+            dy2, dyt = K.pack_split(dy.view(B, Cout, H * W), want_plain=ctx.needs_input_grad[1], want_tr=ctx.needs_input_grad[0],
+                                    mask=y.view(B, Cout, H * W) if fuse_mask else None)
             if ctx.needs_input_grad[0]:
                 dx = K.conv3x3_nhwc_f32out(dyt, K.conv3x3_nhwc_pack(K.split3_weights(_c(w), 0), 1), None, w.shape[1], H, W)
             if ctx.needs_input_grad[1]:

@@ -310,18 +310,24 @@ int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream,
  *                             order; backward g (B, HW, C) bf16 = df * LeakyReLU'(y)
  *   gd_nhwc_to_nchw16       : g (B, HW, C) bf16 -> gt (B, C, HW) bf16 (the dy_bf16 operand of gd_conv3x3_wgrad) and,
  *                             when csum != NULL, csum (C) fp32 = per-channel sums (the bias gradient; overwritten)
- * ---------------------------------------------------------------------------------------- */
+ * ----------------------------------------------------------------------------------------  *   split (all eight entry points; operand mode "x3" of set_precision("mixed")): 1 = every pixel-major bf16 ACTIVATION or
+ *   GRADIENT tensor named above holds 3 C channels per pixel, the C fp32 values split as [hi | lo | hi] with hi = bf16(v),
+ *   lo = bf16(v - hi): the operand the conv kernels take unchanged against weights split [hi ; hi ; lo] along the contraction
+ *   axis (gd_split3_weights), three bf16 MFMAs per product, ~2^-16 relative.  The conv entry points then take K (forward)
+ *   resp. M (data gradient) = the 3 C PHYSICAL channel count of their input and the logical count of their output;
+ *   gd_nhwc_to_nchw16 writes two (B, C, HW) images, hi then lo, and the sums of hi + lo.  0 = plain bf16 (C channels).
+ */
 int gd_disc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co, float slope,
-                     void* y, void* stream);
-int gd_disc_stem_wgrad(const void* g, const float* img, int B, int Ci, int H, int W, int Co, float* dw, float* db, void* stream);
-int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream);
+                     void* y, int split, void* stream);
+int gd_disc_stem_wgrad(const void* g, const float* img, int B, int Ci, int H, int W, int Co, float* dw, float* db, int split, void* stream);
+int gd_disc_stem_dgrad(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, int split, void* stream);
 int gd_conv3x3_nhwc_s2(const void* x, const void* wpack, const float* bias, void* y, int B, int H, int W, int K, int M, int act,
-                       float slope, void* stream);
+                       float slope, int split, void* stream);
 int gd_conv3x3_nhwc_s2_dgrad(const void* dy, const void* wpack_t, const void* act_out, float slope, void* dx, int B, int H,
-                             int W, int K, int M, void* stream);
-int gd_nhwc_flatten_fwd(const void* y, int B, int HW, int C, float* f, void* stream);
-int gd_nhwc_flatten_bwd(const float* df, const void* y, float slope, int B, int HW, int C, void* g, void* stream);
-int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum, void* stream);
+                             int W, int K, int M, int split, void* stream);
+int gd_nhwc_flatten_fwd(const void* y, int B, int HW, int C, float* f, int split, void* stream);
+int gd_nhwc_flatten_bwd(const float* df, const void* y, float slope, int B, int HW, int C, void* g, int split, void* stream);
+int gd_nhwc_to_nchw16(const void* g, int B, int HW, int C, void* gt, float* csum, int split, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * PAM, fused (flash) form with 16-bit MFMA operands and fp32 softmax statistics (generator.py:115-122).
@@ -433,6 +439,11 @@ int gd_chan_dot(const float* a, long a_bs, const float* o, long o_bs, int B, int
 int gd_pack_16_split(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift, int relu,
                      void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr, long t_bs, int ldt,
                      long t_cs, int t_ncopy, int t_pattern, void* stream);
+/* the same with the ReLU backward fused (autograd of nn.ReLU behind a conv, losses.py:41 / generator.py:219): `mask` (B, R, Cc)
+ * fp32, batch stride m_bs, is the ReLU's output; elements whose mask value is not positive are packed as zero */
+int gd_pack_16_split_masked(const float* s, long s_bs, int B, int R, int Cc, const float* row_scale, const float* row_shift,
+                            int relu, void* plain, long p_bs, int ldp, long p_cs, int p_ncopy, int p_pattern, void* tr, long t_bs,
+                            int ldt, long t_cs, int t_ncopy, int t_pattern, const float* mask, long m_bs, void* stream);
 int gd_split3_weights(const float* w, long A, long Bn, long Cn, float* out, void* stream);
 /* fp16 operand mode of gd_pam_flash_bwd (autograd of generator.py:115-122 under set_precision("fp16" | "mixed")): IEEE
  * fp16 loses everything below 6e-8, and gamma * dOut of a real training step sits below that.  All outputs of the backward

@@ -536,6 +536,72 @@ def test_disc_stem_flatten_kernels(gd, ci, hw):
     assert torch.equal(_nchw(gb), gr)
 
 
+def _nhwc_split(t):      # (B, C, H, W) fp32 cpu -> (B, H, W, 3 C) bf16 gpu, [hi | lo | hi]
+    hi = bf16_round(t)
+    lo = bf16_round(t - hi)
+    return torch.cat([hi, lo, hi], 1).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def _nchw_split(t):      # (B, H, W, 3 C) bf16 gpu -> (B, C, H, W) fp32 cpu = hi + lo; the second hi copy must equal the first
+    v = t.float().cpu().permute(0, 3, 1, 2)
+    C = v.shape[1] // 3
+    assert torch.equal(v[:, :C], v[:, 2 * C:])
+    return (v[:, :C] + v[:, C:2 * C]).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32, 128), (1, 128, 17, 35, 256), (2, 32, 9, 70, 24)])
+def test_disc_trunk_kernels_on_split_activations_vs_fp64(gd, shape):
+    """operand mode "x3" of the Discriminator1 trunk: the stride-2 forward, its parity-split data gradient, the transposer
+    and the weight gradient's three accumulating launches, the stem kernels and flatten on [hi | lo | hi] pixel-major
+    tensors (split = 1) against torch in fp64 on the UNROUNDED operands: ~2^-16, asserted at 1e-4 where plain bf16
+    storage gives 1e-2."""
+    _, K = _ops()
+    B, Cin, H, W, Cout = shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = seeded((B, Cin, H, W), 251)
+    w = seeded((Cout, Cin, 3, 3), 252, 1.0 / math.sqrt(9 * Cin))
+    bias = seeded((Cout,), 253, 0.1)
+    xs = _nhwc_split(x)
+    y = K.conv3x3_nhwc_s2(xs, K.conv3x3_nhwc_pack(K.split3_weights(w.to(DEV), 1), 0), bias.to(DEV), Cout, 2, 0.2, split=True)
+    yr = F.leaky_relu(F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1), 0.2).float()
+    assert y.shape == (B, Ho, Wo, 3 * Cout)
+    assert_close(_nchw_split(y), yr, 1e-4, "split s2 forward")
+    dy = seeded((B, Cout, Ho, Wo), 254)
+    act = seeded((B, Cin, H, W), 255)
+    dx = K.conv3x3_nhwc_s2_dgrad(_nhwc_split(dy), K.conv3x3_nhwc_pack(K.split3_weights(w.to(DEV), 0), 2), _nhwc_split(act), 0.2,
+                                 split=True)
+    dxr = (torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), stride=2, padding=1)
+           * torch.where(act > 0, 1.0, 0.2).double()).float()
+    assert_close(_nchw_split(dx), dxr, 1e-4, "split s2 dgrad with LeakyReLU mask")
+    gt, cs = K.nhwc_to_nchw16(_nhwc_split(dy), True, split=True)
+    assert gt.shape == (2, B, Cout, Ho, Wo)
+    assert torch.equal(gt[0].float().cpu(), bf16_round(dy)) and torch.equal(gt[1].float().cpu(), bf16_round(dy - bf16_round(dy)))
+    assert_close(cs, dy.sum((0, 2, 3)), 1e-4, "channel sums of hi + lo")
+    dw, db = K.conv3x3_wgrad_nhwc(_nhwc_split(dy), xs, 2, True, split=True)
+    dwr = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), stride=2, padding=1).float()
+    assert_close(dw, dwr, 1e-4, "split nhwc wgrad")
+    assert_close(db, dy.sum((0, 2, 3)), 1e-4, "bias gradient")
+    # stem (fp32 FMAs from the image) writing / reading split tensors, and flatten
+    img = seeded((B, 1, 2 * H, 2 * W), 256)
+    ws_ = seeded((64, 1, 3, 3), 257, 0.3)
+    bs_ = seeded((64,), 258, 0.1)
+    a = K.disc_stem_fwd(img.to(DEV), ws_.to(DEV), bs_.to(DEV), 0.2, split=True)
+    ar = F.leaky_relu(F.conv2d(img, ws_, bs_, stride=2, padding=1), 0.2)
+    assert_close(_nchw_split(a), ar, 1e-5, "split stem fwd")
+    g = seeded((B, 64, H, W), 259)
+    dws, dbs = K.disc_stem_wgrad(_nhwc_split(g), img.to(DEV), split=True)
+    assert_close(dws, torch.nn.grad.conv2d_weight(img, (64, 1, 3, 3), g, stride=2, padding=1), 1e-4, "split stem wgrad")
+    assert_close(dbs, g.sum((0, 2, 3)), 1e-4, "split stem bias gradient")
+    dimg = K.disc_stem_dgrad(_nhwc_split(g), ws_.to(DEV), 2 * H, 2 * W, split=True)
+    assert_close(dimg, torch.nn.grad.conv2d_input((B, 1, 2 * H, 2 * W), ws_, g, stride=2, padding=1), 1e-4, "split stem dgrad")
+    f = K.nhwc_flatten_fwd(a, split=True)
+    assert torch.equal(f.cpu(), _nchw_split(a).flatten(1))
+    df = seeded(tuple(f.shape), 260)
+    gb = K.nhwc_flatten_bwd(df.to(DEV), a, 0.2, split=True)
+    gr = df.view(B, 64, H, W) * torch.where(_nchw_split(a) > 0, 1.0, 0.2)
+    assert_close(_nchw_split(gb), gr, 1e-5, "split flatten bwd")
+
+
 @pytest.mark.parametrize("ci", [1, 3])
 def test_nhwc_stem_pool_l1(gd, ci):
     _, K = _ops()
@@ -737,6 +803,13 @@ def test_split_pack_layouts_and_weight_split(gd):
         assert ((rec - ref).abs() <= 2.0 ** -16 * ref.abs() + 1e-30 + tol).all()
         rec_t = (tr[..., :C].float() + tr[..., C:2 * C].float()).cpu().transpose(1, 2).reshape(B, C, H, W)
         assert torch.equal(rec_t, rec)
+    # the ReLU backward fused into the pack (gd_pack_16_split_masked): bitwise the pack of act_bwd's result
+    ymask = torch.relu(seeded((B, C, H, W), 55)).to(DEV)
+    xm = x.contiguous()
+    p_ref, t_ref = K.pack_split(K.act_bwd(ymask, xm, 1), want_plain=True)
+    p_got, t_got = K.pack_split(xm, want_plain=True, mask=ymask)
+    assert torch.equal(p_ref.view(torch.int16), p_got.view(torch.int16)) and torch.equal(t_ref.view(torch.int16), t_got.view(torch.int16))
+    assert (p_got[0].float().view(B, C, H, W)[ymask <= 0] == 0).all() and (ymask <= 0).float().mean() > 0.3
     w = seeded((24, 40, 3, 3), 54, 0.2).to(DEV)
     whi = bf16_round(w.cpu())
     w1 = K.split3_weights(w, 1).cpu()

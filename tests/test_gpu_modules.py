@@ -385,6 +385,30 @@ def test_discriminator1_bf16_nhwc_trunk_vs_reference_fixture(gd, golden_dir, mon
     assert_close(m.fc1.weight.grad[:8, :64], fx["grad__fc1__weight_head"], 1e-1, "fc1 head", rell2)
 
 
+def test_discriminator1_mixed_split_trunk_vs_reference_fixture(gd, golden_dir, monkeypatch):
+    """mixed mode: the same one-node trunk on SPLIT activations ([hi | lo | hi] pixel-major, weights [hi ; hi ; lo]: three
+    bf16 MFMAs per product) holds the fp32 mode's bounds on the reference fixture -- 1e-4 on y, 1e-3 on the gradients
+    (the bf16 trunk above: 2e-2 / 1e-1)."""
+    from gan_danet_amd import Discriminator1, ops
+    fx = load_golden(golden_dir, "disc1_64x64")
+    m = Discriminator1().to(DEV)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    calls = []
+    orig = ops.Disc1TrunkFn.apply
+    monkeypatch.setattr(ops.Disc1TrunkFn, "apply", lambda *a: (calls.append(1), orig(*a))[1])
+    with gd.precision("mixed"):
+        with torch.no_grad():
+            m(x)
+        fill_module(m)
+        y = m(x)
+        y.backward(fx["go"].to(DEV))
+    assert len(calls) == 2, "the pixel-major trunk did not run"
+    assert_close(y, fx["y"], 1e-4, "y")
+    assert_close(x.grad, fx["gx"], 1e-3, "dx", rell2)
+    _check_param_grads(m, fx, 1e-3, rell2)
+    assert_close(m.fc1.weight.grad[:8, :64], fx["grad__fc1__weight_head"], 1e-3, "fc1 head")
+
+
 @pytest.mark.parametrize("ci,hw,b", [(1, (52, 44), 3), (3, (40, 72), 2), (1, (128, 160), 2)])
 def test_discriminator1_nhwc_trunk_ragged_vs_oracle(gd, ci, hw, b):
     """odd / ragged sizes through every tile-edge branch of the stride-2 kernels (52 -> 26 -> 13 -> 7 -> 4 ...), 1 and 3
