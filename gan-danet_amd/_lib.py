@@ -116,7 +116,7 @@ SIGNATURES = {
     "gd_chan_dot": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _p, _p, _p]),
     "gd_pam_f16_scale": (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "gd_conv3x3_nhwc_pack": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
-    "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gd_conv3x3_nhwc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gd_conv3x3_nhwc_f32out": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p]),
     "gd_disc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _f, _p, _i, _p]),
     "gd_disc_stem_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
@@ -126,12 +126,12 @@ SIGNATURES = {
     "gd_nhwc_flatten_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "gd_nhwc_flatten_bwd": (_i, [_p, _p, _f, _i, _i, _i, _p, _i, _p]),
     "gd_nhwc_to_nchw16": (_i, [_p, _i, _i, _i, _p, _p, _i, _p]),
-    "gd_nhwc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
-    "gd_nhwc_stem_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
-    "gd_nhwc_maxpool2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p]),
-    "gd_nhwc_maxpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
-    "gd_nhwc_l1": (_i, [_p, _p, _l, _p, _i, _p, _p]),
-    "gd_nhwc_l1_grad": (_i, [_p, _p, _l, _p, _i, _p, _p]),
+    "gd_nhwc_stem_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _i, _p]),
+    "gd_nhwc_stem_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "gd_nhwc_maxpool2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p]),
+    "gd_nhwc_maxpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "gd_nhwc_l1": (_i, [_p, _p, _l, _p, _i, _p, _i, _p]),
+    "gd_nhwc_l1_grad": (_i, [_p, _p, _l, _p, _i, _p, _i, _p]),
     "gd_shift_sum9_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "gd_shift_sum9_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "gd_combine_inputs": (_i, [_p, _i, _i, _i, _f, _p, _i, _i, _i, _f, _p, _i, _i, _i, _p]),

@@ -425,11 +425,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
                         if (!((mk.y >> 16) & 0x7FFFu) || (mk.y >> 31)) v[3] = 0.f;
                     }
                     if (a.res) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(a.res + pbase + m);
-                        v[0] += gd_bf2f((unsigned short)(rr.x & 0xFFFFu));
-                        v[1] += gd_bf2f((unsigned short)(rr.x >> 16));
-                        v[2] += gd_bf2f((unsigned short)(rr.y & 0xFFFFu));
-                        v[3] += gd_bf2f((unsigned short)(rr.y >> 16));
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {          // split: res = hi + lo
+                            if (part && !a.osplit) break;
+                            const uint2 rr = *reinterpret_cast<const uint2*>(a.res + pbase + part * a.M + m);
+                            v[0] += gd_bf2f((unsigned short)(rr.x & 0xFFFFu));
+                            v[1] += gd_bf2f((unsigned short)(rr.x >> 16));
+                            v[2] += gd_bf2f((unsigned short)(rr.y & 0xFFFFu));
+                            v[3] += gd_bf2f((unsigned short)(rr.y >> 16));
+                        }
                     }
                     if (a.y32) {
                         // fp32 NCHW: for one channel the 32 lanes of a half-wave are 32 consecutive pixels (128-byte rows)
@@ -673,13 +677,15 @@ static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias,
     return 0;
 }
 
+// split = 1 (operand mode "x3"): x holds K = 3 Cin physical channels [hi | lo | hi], wpack comes from weights split [hi ; hi ; lo]
+// along the contraction axis, and y / mask / res hold 3 M channels per pixel (mask: the sign of the hi part; res: hi + lo)
 extern "C" int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bias, const void* mask, const void* res,
-                               void* y, int B, int H, int W, int K, int M, int relu, void* stream) {
+                               void* y, int B, int H, int W, int K, int M, int relu, int split, void* stream) {
     GD_CHECK_ARG(x && wpack && y, "gd_conv3x3_nhwc: null pointer");
     GD_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && K > 0 && M > 0 && K % 8 == 0 && M % 8 == 0,
                  "gd_conv3x3_nhwc: channel counts must be multiples of 8");
-    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M < (1L << 31), "gd_conv3x3_nhwc: image too large");
-    return nhwc_conv_launch(x, wpack, bias, mask, res, y, B, H, W, K, M, 1, relu ? 1 : 0, 0.f, stream);
+    GD_CHECK_ARG((long)H * W * K < (1L << 31) && (long)H * W * M * (split ? 3 : 1) < (1L << 31), "gd_conv3x3_nhwc: image too large");
+    return nhwc_conv_launch(x, wpack, bias, mask, res, y, B, H, W, K, M, 1, relu ? 1 : 0, 0.f, stream, nullptr, 0, split ? 1 : 0);
 }
 
 // stride 1 with an fp32 NCHW result: x (B, H, W, K) bf16 pixel-major -> y32 (B, M, H, W) fp32 (batch stride y_bs elements),

@@ -22,12 +22,37 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
     return v;
 }
 
+// Split activations (operand mode "x3" of set_precision("mixed")): a pixel's C logical channels stored as 3 C bf16,
+// [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) (see disc_nhwc.hip / gd_pack_16_split).  row = the pixel's first element.
+__device__ __forceinline__ void store8(unsigned short* row, int C, int c8, const float* v, int split) {
+    const u32x4_t hi = pack8(v);
+    *reinterpret_cast<u32x4_t*>(row + c8) = hi;
+    if (split) {
+        float r[8];
+        unpack8(hi, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = v[k] - r[k];
+        *reinterpret_cast<u32x4_t*>(row + C + c8) = pack8(r);
+        *reinterpret_cast<u32x4_t*>(row + 2 * C + c8) = hi;
+    }
+}
+__device__ __forceinline__ void load8(const unsigned short* row, int C, int c8, float* v, int split) {
+    unpack8(*reinterpret_cast<const u32x4_t*>(row + c8), v);
+    if (split) {
+        float l[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(row + C + c8), l);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += l[k];
+    }
+}
+
 // ---- stem: fp32 NCHW image (B, Ci <= 4, H, W) -> conv3x3 p1 (+bias, ReLU) -> NHWC bf16 (B, H, W, Co) --------------
 // thread = (pixel, output-channel octet); weights in LDS as [ci][tap][co]
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img, int Ci, int H, int W,
                                                       const float* __restrict__ w, const float* __restrict__ bias, int Co,
-                                                      int relu, unsigned short* __restrict__ y, long npix_total) {
+                                                      int relu, unsigned short* __restrict__ y, long npix_total, int split) {
     extern __shared__ float wl[];                       // Ci * 9 * Co
+    const int RS = split ? 3 * Co : Co;
     for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
         const int co = i % Co, t = (i / Co) % 9, ci = i / (9 * Co);
         wl[i] = w[((long)co * Ci + ci) * 9 + t];
@@ -65,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             if (relu)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
-            *reinterpret_cast<u32x4_t*>(y + p * 64 + o8) = pack8(acc);
+            store8(y + p * RS, 64, o8, acc, split);
         }
         return;
     }
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         if (relu)
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
-        *reinterpret_cast<u32x4_t*>(y + p * Co + o8) = pack8(acc);
+        store8(y + p * RS, Co, o8, acc, split);
     }
 }
 
@@ -105,8 +130,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 constexpr int SB_T = 16, SB_HT = SB_T + 2, SB_NH = SB_HT * SB_HT;
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const unsigned short* __restrict__ g, int Ci, int H, int W,
                                                       const float* __restrict__ w, int Co, float* __restrict__ dimg,
-                                                      int tiles_x) {
+                                                      int tiles_x, int split) {
     extern __shared__ float smem[];
+    const int RS = split ? 3 * Co : Co;
     float* wl = smem;                                   // [ci][tap][co]
     float* T = smem + Ci * 9 * Co;                      // [ci*9 + tap][haloed pixel]
     for (int i = threadIdx.x; i < Ci * 9 * Co; i += 256) {
@@ -127,10 +153,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const unsigned short* __r
 #pragma unroll
             for (int k = 0; k < 9; ++k) t[k] = 0.f;
             if (inside) {
-                const unsigned short* gp = g + (((long)b * H + qy) * W + qx) * Co;
+                const unsigned short* gp = g + (((long)b * H + qy) * W + qx) * RS;
                 for (int o8 = 0; o8 < Co; o8 += 8) {
                     float f[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(gp + o8), f);
+                    load8(gp, Co, o8, f, split);
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const float* wp = wl + (ci * 9 + k) * Co + o8;      // uniform address: LDS broadcast
@@ -159,45 +185,45 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const unsigned short* __r
 
 // ---- 2x2 max pooling, NHWC bf16; thread = (output pixel, channel octet) --------------------------------------------
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const unsigned short* __restrict__ x, int H, int W, int C,
-                                                      unsigned short* __restrict__ y, long total) {
-    const int oct = C / 8, Ho = H / 2, Wo = W / 2;
+                                                      unsigned short* __restrict__ y, long total, int split) {
+    const int oct = C / 8, Ho = H / 2, Wo = W / 2, RS = split ? 3 * C : C;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long p = idx / oct;
         const int o8 = (int)(idx - p * oct) * 8;
         const long b = p / ((long)Ho * Wo);
         const int rem = (int)(p - b * (long)Ho * Wo);
         const int oy = rem / Wo, ox = rem - oy * Wo;
-        const unsigned short* xp = x + ((b * H + 2 * oy) * (long)W + 2 * ox) * C + o8;
+        const unsigned short* xp = x + ((b * H + 2 * oy) * (long)W + 2 * ox) * RS;
         float m[8], f[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(xp), m);
-        const long offs[3] = {(long)C, (long)W * C, (long)W * C + C};
+        load8(xp, C, o8, m, split);
+        const long offs[3] = {(long)RS, (long)W * RS, (long)W * RS + RS};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            unpack8(*reinterpret_cast<const u32x4_t*>(xp + offs[q]), f);
+            load8(xp + offs[q], C, o8, f, split);
 #pragma unroll
             for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], f[k]);
         }
-        *reinterpret_cast<u32x4_t*>(y + p * C + o8) = pack8(m);
+        store8(y + p * RS, C, o8, m, split);          // a maximum of values hi + lo splits back into the same hi, lo
     }
 }
 // dx = dy at the FIRST maximum of each window in row-major order (ATen's tie rule), else 0; with relu_mask the
 // result is also gated by x > 0 (backward of the ReLU that produced x)
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
                                                       int H, int W, int C, int relu_mask, unsigned short* __restrict__ dx,
-                                                      long total) {
-    const int oct = C / 8, Ho = H / 2, Wo = W / 2;
+                                                      long total, int split) {
+    const int oct = C / 8, Ho = H / 2, Wo = W / 2, RS = split ? 3 * C : C;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long p = idx / oct;
         const int o8 = (int)(idx - p * oct) * 8;
         const long b = p / ((long)Ho * Wo);
         const int rem = (int)(p - b * (long)Ho * Wo);
         const int oy = rem / Wo, ox = rem - oy * Wo;
-        const long base = ((b * H + 2 * oy) * (long)W + 2 * ox) * C + o8;
-        const long offs[4] = {0L, (long)C, (long)W * C, (long)W * C + C};
+        const long base = ((b * H + 2 * oy) * (long)W + 2 * ox) * RS;
+        const long offs[4] = {0L, (long)RS, (long)W * RS, (long)W * RS + RS};
         float v[4][8], g[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) unpack8(*reinterpret_cast<const u32x4_t*>(x + base + offs[q]), v[q]);
-        unpack8(*reinterpret_cast<const u32x4_t*>(dy + p * C + o8), g);
+        for (int q = 0; q < 4; ++q) load8(x + base + offs[q], C, o8, v[q], split);
+        load8(dy + p * RS, C, o8, g, split);
         float out[4][8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -211,19 +237,28 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const unsigned short* __r
             for (int q = 0; q < 4; ++q) out[q][k] = q == arg ? gk : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(dx + base + offs[q]) = pack8(out[q]);
+        for (int q = 0; q < 4; ++q) store8(dx + base + offs[q], C, o8, out[q], split);
     }
 }
 
 // ---- L1 feature distance: partial sums of |a - b| (two-stage, deterministic) and its gradient ----------------------
+// split_c: 0 = plain tensors of n8 octets; C > 0 = split tensors of C logical channels per pixel (n8 LOGICAL octets)
 __global__ __launch_bounds__(256) void l1_sum_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
-                                                    long n8, float* __restrict__ ws) {
+                                                    long n8, float* __restrict__ ws, int split_c) {
     __shared__ float red[4];
     float s = 0.f;
+    const int oct = split_c ? split_c / 8 : 1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         float fa[8], fb[8];
-        unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
-        unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+        if (split_c) {
+            const long px = i / oct;
+            const int o8 = (int)(i - px * oct) * 8;
+            load8(a + px * 3 * split_c, split_c, o8, fa, 1);
+            load8(b + px * 3 * split_c, split_c, o8, fb, 1);
+        } else {
+            unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
+            unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += fabsf(fa[k] - fb[k]);
     }
@@ -246,12 +281,20 @@ __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__
 // g = (*upstream) * inv_n * sign(a - b), gated by a > 0 when relu_mask (a is a ReLU output)
 __global__ __launch_bounds__(256) void l1_grad_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
                                                      long n8, const float* __restrict__ upstream, float inv_n, int relu_mask,
-                                                     unsigned short* __restrict__ g) {
+                                                     unsigned short* __restrict__ g, int split_c) {
     const float k = (*upstream) * inv_n;
+    const int oct = split_c ? split_c / 8 : 1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         float fa[8], fb[8], o[8];
-        unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
-        unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+        const long px = i / oct;
+        const int o8 = (int)(i - px * oct) * 8;
+        if (split_c) {
+            load8(a + px * 3 * split_c, split_c, o8, fa, 1);
+            load8(b + px * 3 * split_c, split_c, o8, fb, 1);
+        } else {
+            unpack8(reinterpret_cast<const u32x4_t*>(a)[i], fa);
+            unpack8(reinterpret_cast<const u32x4_t*>(b)[i], fb);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float dv = fa[j] - fb[j];
@@ -259,7 +302,8 @@ __global__ __launch_bounds__(256) void l1_grad_kernel(const unsigned short* __re
             if (relu_mask && !(fa[j] > 0.f)) v = 0.f;
             o[j] = v;
         }
-        reinterpret_cast<u32x4_t*>(g)[i] = pack8(o);
+        if (split_c) store8(g + px * 3 * split_c, split_c, o8, o, 1);
+        else reinterpret_cast<u32x4_t*>(g)[i] = pack8(o);
     }
 }
 
@@ -275,16 +319,16 @@ static inline int grid_n(long n, int cap = 16384) {
 #define NS(s) ((hipStream_t)(s))
 
 extern "C" int gd_nhwc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co,
-                                int relu, void* y, void* stream) {
+                                int relu, void* y, int split, void* stream) {
     GD_CHECK_ARG(img && w && y && B > 0 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Ci * 9 * Co * 4 <= 65536,
                  "gd_nhwc_stem_fwd: needs Ci <= 4, Co % 8 == 0");
     const long npix = (long)B * H * W;
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid_n(npix * (Co / 8))), dim3(256), (size_t)Ci * 9 * Co * 4, NS(stream), img, Ci,
-                       H, W, w, bias, Co, relu, (unsigned short*)y, npix);
+                       H, W, w, bias, Co, relu, (unsigned short*)y, npix, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg,
+extern "C" int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, int split,
                                 void* stream) {
     GD_CHECK_ARG(g && w && dimg && B > 0 && B <= 65535 && Ci > 0 && Ci <= 4 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0,
                  "gd_nhwc_stem_bwd: needs Ci <= 4, Co % 8 == 0");
@@ -292,43 +336,47 @@ extern "C" int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, cons
     GD_CHECK_ARG(lds <= 64 * 1024, "gd_nhwc_stem_bwd: Ci * Co too large for the LDS tile");
     const int tiles_x = (W + SB_T - 1) / SB_T, tiles_y = (H + SB_T - 1) / SB_T;
     hipLaunchKernelGGL(stem_bwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256), lds, NS(stream), (const unsigned short*)g, Ci,
-                       H, W, w, Co, dimg, tiles_x);
+                       H, W, w, Co, dimg, tiles_x, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, void* stream) {
+extern "C" int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, int split, void* stream) {
     GD_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
                  "gd_nhwc_maxpool2_fwd: needs even H, W and C % 8 == 0");
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)x, H, W, C,
-                       (unsigned short*)y, total);
+                       (unsigned short*)y, total, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx,
-                                    void* stream) {
+                                    int split, void* stream) {
     GD_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
                  "gd_nhwc_maxpool2_bwd: needs even H, W and C % 8 == 0");
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_n(total)), dim3(256), 0, NS(stream), (const unsigned short*)x,
-                       (const unsigned short*)dy, H, W, C, relu_mask, (unsigned short*)dx, total);
+                       (const unsigned short*)dy, H, W, C, relu_mask, (unsigned short*)dx, total, split);
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, void* stream) {
+// split_c (here and in gd_nhwc_l1_grad): 0 = plain tensors of n elements; C = split tensors ([hi | lo | hi], 3 C bf16 per pixel) of
+// n LOGICAL elements with C channels per pixel
+extern "C" int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, int split_c, void* stream) {
     GD_CHECK_ARG(a && b && out && ws && n > 0 && n % 8 == 0, "gd_nhwc_l1: n must be a positive multiple of 8");
+    GD_CHECK_ARG(split_c >= 0 && split_c % 8 == 0 && (split_c == 0 || n % split_c == 0), "gd_nhwc_l1: bad split channel count");
     const int g = grid_n(n / 8, 1024);
     hipLaunchKernelGGL(l1_sum_kernel, dim3(g), dim3(256), 0, NS(stream), (const unsigned short*)a, (const unsigned short*)b,
-                       n / 8, ws);
+                       n / 8, ws, split_c);
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, NS(stream), ws, g, (float)(1.0 / (double)n), out, accumulate);
     GD_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g,
+extern "C" int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, int split_c,
                                void* stream) {
     GD_CHECK_ARG(a && b && upstream && g && n > 0 && n % 8 == 0, "gd_nhwc_l1_grad: n must be a positive multiple of 8");
+    GD_CHECK_ARG(split_c >= 0 && split_c % 8 == 0 && (split_c == 0 || n % split_c == 0), "gd_nhwc_l1_grad: bad split channel count");
     hipLaunchKernelGGL(l1_grad_kernel, dim3(grid_n(n / 8)), dim3(256), 0, NS(stream), (const unsigned short*)a,
-                       (const unsigned short*)b, n / 8, upstream, (float)(1.0 / (double)n), relu_mask, (unsigned short*)g);
+                       (const unsigned short*)b, n / 8, upstream, (float)(1.0 / (double)n), relu_mask, (unsigned short*)g, split_c);
     GD_LAUNCH_CHECK();
     return 0;
 }

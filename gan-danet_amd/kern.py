@@ -897,17 +897,18 @@ def conv3x3_nhwc_pack(w: Tensor, transposed: bool) -> Tensor:
 
 
 def conv3x3_nhwc(x: Tensor, wpack: Tensor, bias: Optional[Tensor], M: int, relu: bool = False,
-                 mask: Optional[Tensor] = None, res: Optional[Tensor] = None) -> Tensor:
-    """x (B, H, W, K) bf16 -> (B, H, W, M) bf16: [mask > 0] * act(conv3x3(x) + bias) + res"""
+                 mask: Optional[Tensor] = None, res: Optional[Tensor] = None, split: bool = False) -> Tensor:
+    """x (B, H, W, K) bf16 -> (B, H, W, M) bf16: [mask > 0] * act(conv3x3(x) + bias) + res; split: K = 3 Cin physical
+    channels, wpack from split weights, y / mask / res with 3 M channels ([hi | lo | hi])"""
     _bf(x, "nhwc conv input")
     B, H, W, Kc = x.shape
-    y = torch.empty(B, H, W, M, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(B, H, W, (3 if split else 1) * M, device=x.device, dtype=torch.bfloat16)
     for t, nm in ((mask, "mask"), (res, "res")):
         if t is not None and (_bf(t, nm).shape != y.shape):
             raise L.GandanetError(f"conv3x3_nhwc: {nm} {tuple(t.shape)} does not match the output {tuple(y.shape)}")
     with _Bracket("conv3x3_nhwc", 2.0 * 9 * Kc * M * H * W * B):
         L.check(lib().gd_conv3x3_nhwc(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(mask), _ptr(res), _ptr(y), B, H, W, Kc, M,
-                                      int(relu), _stream()), "gd_conv3x3_nhwc")
+                                      int(relu), int(split), _stream()), "gd_conv3x3_nhwc")
     return y
 
 
@@ -1125,54 +1126,63 @@ def conv3x3_wgrad_nhwc(g: Tensor, x: Tensor, stride: int, want_bias: bool, split
     return dw, db
 
 
-def nhwc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+def nhwc_stem_fwd(img: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool, split: bool = False) -> Tensor:
+    """``split`` (here and in the nhwc_* functions below): the pixel-major tensors carry 3 C channels per pixel, the values
+    split [hi | lo | hi] (operand mode "x3")"""
     _dense(img, "stem image"), _dense(w, "stem weight")
     B, Ci, H, W = img.shape
     Co = w.shape[0]
     if w.shape[1] != Ci:
         raise L.GandanetError(f"nhwc_stem_fwd: weight {tuple(w.shape)} does not match image {tuple(img.shape)}")
-    y = torch.empty(B, H, W, Co, device=img.device, dtype=torch.bfloat16)
-    L.check(lib().gd_nhwc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, int(relu), _ptr(y), _stream()),
+    y = torch.empty(B, H, W, (3 if split else 1) * Co, device=img.device, dtype=torch.bfloat16)
+    L.check(lib().gd_nhwc_stem_fwd(_ptr(img), B, Ci, H, W, _ptr(w), _ptr(bias), Co, int(relu), _ptr(y), int(split), _stream()),
             "gd_nhwc_stem_fwd")
     return y
 
 
-def nhwc_stem_bwd(g: Tensor, w: Tensor) -> Tensor:
+def nhwc_stem_bwd(g: Tensor, w: Tensor, split: bool = False) -> Tensor:
     _bf(g, "stem gradient"), _dense(w, "stem weight")
     B, H, W, Co = g.shape
+    Co //= 3 if split else 1
     Ci = w.shape[1]
     dimg = torch.empty(B, Ci, H, W, device=g.device, dtype=torch.float32)
-    L.check(lib().gd_nhwc_stem_bwd(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), _stream()), "gd_nhwc_stem_bwd")
+    L.check(lib().gd_nhwc_stem_bwd(_ptr(g), B, Ci, H, W, _ptr(w), Co, _ptr(dimg), int(split), _stream()), "gd_nhwc_stem_bwd")
     return dimg
 
 
-def nhwc_maxpool2_fwd(x: Tensor) -> Tensor:
+def nhwc_maxpool2_fwd(x: Tensor, split: bool = False) -> Tensor:
     _bf(x, "pool input")
     B, H, W, Cn = x.shape
     y = torch.empty(B, H // 2, W // 2, Cn, device=x.device, dtype=torch.bfloat16)
-    L.check(lib().gd_nhwc_maxpool2_fwd(_ptr(x), B, H, W, Cn, _ptr(y), _stream()), "gd_nhwc_maxpool2_fwd")
+    L.check(lib().gd_nhwc_maxpool2_fwd(_ptr(x), B, H, W, Cn // (3 if split else 1), _ptr(y), int(split), _stream()),
+            "gd_nhwc_maxpool2_fwd")
     return y
 
 
-def nhwc_maxpool2_bwd(x: Tensor, dy: Tensor, relu_mask: bool) -> Tensor:
+def nhwc_maxpool2_bwd(x: Tensor, dy: Tensor, relu_mask: bool, split: bool = False) -> Tensor:
     _bf(x, "pool input"), _bf(dy, "pool dy")
     B, H, W, Cn = x.shape
     dx = torch.empty_like(x)
-    L.check(lib().gd_nhwc_maxpool2_bwd(_ptr(x), _ptr(dy), B, H, W, Cn, int(relu_mask), _ptr(dx), _stream()),
+    L.check(lib().gd_nhwc_maxpool2_bwd(_ptr(x), _ptr(dy), B, H, W, Cn // (3 if split else 1), int(relu_mask), _ptr(dx), int(split),
+                                       _stream()),
             "gd_nhwc_maxpool2_bwd")
     return dx
 
 
-def nhwc_l1(a: Tensor, b: Tensor, out: Tensor, accumulate: bool) -> None:
-    """out[0] (+)= mean |a - b| over bf16 tensors of equal shape"""
+def nhwc_l1(a: Tensor, b: Tensor, out: Tensor, accumulate: bool, split: bool = False) -> None:
+    """out[0] (+)= mean |a - b| over bf16 tensors of equal shape (split: (..., 3 C) tensors of hi + lo values)"""
     _bf(a, "l1 a"), _bf(b, "l1 b")
     ws = torch.empty(1024, device=a.device, dtype=torch.float32)
-    L.check(lib().gd_nhwc_l1(_ptr(a), _ptr(b), a.numel(), _ptr(out), int(accumulate), _ptr(ws), _stream()), "gd_nhwc_l1")
+    sc = a.shape[-1] // 3 if split else 0
+    L.check(lib().gd_nhwc_l1(_ptr(a), _ptr(b), a.numel() // (3 if split else 1), _ptr(out), int(accumulate), _ptr(ws), sc,
+                             _stream()), "gd_nhwc_l1")
 
 
-def nhwc_l1_grad(a: Tensor, b: Tensor, upstream: Tensor, relu_mask: bool) -> Tensor:
+def nhwc_l1_grad(a: Tensor, b: Tensor, upstream: Tensor, relu_mask: bool, split: bool = False) -> Tensor:
     _bf(a, "l1 a"), _bf(b, "l1 b"), _dense(upstream, "upstream gradient")
     g = torch.empty_like(a)
-    L.check(lib().gd_nhwc_l1_grad(_ptr(a), _ptr(b), a.numel(), _ptr(upstream), int(relu_mask), _ptr(g), _stream()),
+    sc = a.shape[-1] // 3 if split else 0
+    L.check(lib().gd_nhwc_l1_grad(_ptr(a), _ptr(b), a.numel() // (3 if split else 1), _ptr(upstream), int(relu_mask), _ptr(g), sc,
+                                  _stream()),
             "gd_nhwc_l1_grad")
     return g

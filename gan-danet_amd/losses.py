@@ -2,6 +2,7 @@
 BCE-with-logits / MSE criteria the notebook takes from torch.nn (GAN_DANet_train.ipynb:L190-191)."""
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Optional, Sequence, Set
 
@@ -94,16 +95,18 @@ class PerceptualLoss(nn.Module):
             i += 1
         return feats
 
-    def _nhwc_plan(self):
+    def _nhwc_plan(self, split: bool = False):
         """layer plan + packed operators of the pixel-major bf16 path, or None when the configuration is not
         served by it (taps off ReLU indices or directly before a pool, non-VGG stacks).  Cached; rebuilt when a
-        weight tensor changes (load_state_dict)."""
+        weight tensor changes (load_state_dict).  ``split``: the operators of the split-bf16 form of the same path
+        (operand mode "x3": activations [hi | lo | hi], weights [hi ; hi ; lo] along the contraction axis)."""
         from . import kern as K
         convs = [m for m in self.vgg if isinstance(m, Conv2d)]
-        version = tuple((id(c.weight), c.weight._version, c.weight.device) for c in convs)
+        version = tuple((id(c.weight), c.weight._version, c.weight.device) for c in convs) + (split,)
         cached = getattr(self, "_nhwc_cache", None)
         if cached is not None and cached[0] == version:
             return cached[1]
+        sw = (lambda w, axis: K.split3_weights(w.contiguous(), axis)) if split else (lambda w, axis: w)
         plan = None
         n = len(self.vgg)
         ok = n >= 2 and isinstance(self.vgg[0], Conv2d) and self.vgg[0].weight.shape[1] == 3 and n - 1 in self.feature_layers
@@ -121,8 +124,8 @@ class PerceptualLoss(nn.Module):
                     ops_.append(("stem", k, m.bias.detach()))
                     pairs.append([k, False, None, 3])
                 else:
-                    ops_.append(("conv", k, m.bias.detach(), K.conv3x3_nhwc_pack(w, False), w.shape[0]))
-                    pairs.append([k, False, K.conv3x3_nhwc_pack(w, True), w.shape[1]])
+                    ops_.append(("conv", k, m.bias.detach(), K.conv3x3_nhwc_pack(sw(w, 1), False), w.shape[0]))
+                    pairs.append([k, False, K.conv3x3_nhwc_pack(sw(w, 0), True), w.shape[1]])
                 if i + 1 in self.feature_layers:
                     taps.add(k)
                 i += 2
@@ -147,10 +150,13 @@ class PerceptualLoss(nn.Module):
         return plan
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        from .config import sixteen_bit
-        if (sixteen_bit("vgg") and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
-                and x.shape[3] % 8 == 0 and self._nhwc_plan() is not None):
-            return _PerceptualNhwcFn.apply(x, y, self)
+        from .config import operand_mode
+        mode = operand_mode("vgg")
+        if mode == "x3" and not VGG_SPLIT_NHWC:
+            mode = "layers"                            # A/B: the per-layer split route (fp32 NCHW between the convs)
+        if (mode in ("16", "x3") and x.shape == y.shape and x.shape[1] in (1, 3) and x.shape[2] % 8 == 0
+                and x.shape[3] % 8 == 0 and self._nhwc_plan(mode == "x3") is not None):
+            return _PerceptualNhwcFn.apply(x, y, self, mode == "x3")
         x3 = x if x.shape[1] == 3 else ops.repeat_channels(x, 3)
         y3 = y if y.shape[1] == 3 else ops.repeat_channels(y, 3)
         with torch.no_grad():
@@ -160,16 +166,21 @@ class PerceptualLoss(nn.Module):
         return ops.weighted_sum([1.0] * len(terms), terms)
 
 
+VGG_SPLIT_NHWC = os.environ.get("GD_VGG_SPLIT_NHWC", "1") != "0"
+
+
 class _PerceptualNhwcFn(torch.autograd.Function):
     """The whole perceptual term as ONE autograd node on pixel-major bf16 activations (bf16 mode): stem conv
     from the fp32 image, gd_conv3x3_nhwc for every other conv (+bias+ReLU fused), NHWC max-pool, L1 feature
     distances; the backward walks the frozen stack with the data-gradient operators, the ReLU backward fused into
-    each producer (mask = the saved ReLU output) and the tap gradients added through the epilogue's ``res``."""
+    each producer (mask = the saved ReLU output) and the tap gradients added through the epilogue's ``res``.
+    ``split`` (operand mode "x3", set_precision("mixed")): the same node on split activations -- every pixel-major tensor
+    holds [hi | lo | hi] (3 C bf16 per pixel), every conv is three bf16 MFMAs per product (~2^-16 relative)."""
 
     @staticmethod
-    def forward(ctx, x, y, mod):
+    def forward(ctx, x, y, mod, split=False):
         from . import kern as K
-        plan = mod._nhwc_plan()
+        plan = mod._nhwc_plan(split)
         x, y = x.contiguous(), y.contiguous()
         dev = x.device
 
@@ -179,11 +190,11 @@ class _PerceptualNhwcFn(torch.autograd.Function):
             a = None
             for op in plan["ops"]:
                 if op[0] == "stem":
-                    a = K.nhwc_stem_fwd(img, plan["w0"][img.shape[1]], op[2], True)
+                    a = K.nhwc_stem_fwd(img, plan["w0"][img.shape[1]], op[2], True, split=split)
                 elif op[0] == "conv":
-                    a = K.conv3x3_nhwc(a, op[3], op[2], op[4], relu=True)
+                    a = K.conv3x3_nhwc(a, op[3], op[2], op[4], relu=True, split=split)
                 else:
-                    a = K.nhwc_maxpool2_fwd(a)
+                    a = K.nhwc_maxpool2_fwd(a, split=split)
                     continue
                 if keep_all or op[1] in plan["taps"]:
                     kept[op[1]] = a
@@ -194,30 +205,30 @@ class _PerceptualNhwcFn(torch.autograd.Function):
             fx = run(x, True)
             loss = torch.zeros(1, device=dev, dtype=torch.float32)
             for n, k in enumerate(sorted(plan["taps"])):
-                K.nhwc_l1(fx[k], fy[k], loss, accumulate=n > 0)
-        ctx.plan, ctx.fx, ctx.fy, ctx.ci = plan, fx, fy, x.shape[1]
+                K.nhwc_l1(fx[k], fy[k], loss, accumulate=n > 0, split=split)
+        ctx.plan, ctx.fx, ctx.fy, ctx.ci, ctx.split = plan, fx, fy, x.shape[1], split
         return loss.view(())
 
     @staticmethod
     def backward(ctx, dloss):
         from . import kern as K
-        plan, fx, fy = ctx.plan, ctx.fx, ctx.fy
+        plan, fx, fy, sp = ctx.plan, ctx.fx, ctx.fy, ctx.split
         up = dloss.reshape(1).to(torch.float32).contiguous()
         pairs = plan["pairs"]                 # forward order: (pair index, followed_by_pool, dgrad pack, Cin)
         top = len(pairs) - 1
-        g = K.nhwc_l1_grad(fx[top], fy[top], up, True)          # w.r.t. the top conv's pre-activation
+        g = K.nhwc_l1_grad(fx[top], fy[top], up, True, split=sp)          # w.r.t. the top conv's pre-activation
         for k in range(top - 1, -1, -1):
             _, pooled, _, _ = pairs[k]
             _, _, pack_t, cin_next = pairs[k + 1]
             if pooled:
-                dpool = K.conv3x3_nhwc(g, pack_t, None, cin_next)
-                g = K.nhwc_maxpool2_bwd(fx[k], dpool, True)
+                dpool = K.conv3x3_nhwc(g, pack_t, None, cin_next, split=sp)
+                g = K.nhwc_maxpool2_bwd(fx[k], dpool, True, split=sp)
             else:
-                res = K.nhwc_l1_grad(fx[k], fy[k], up, True) if k in plan["taps"] else None
-                g = K.conv3x3_nhwc(g, pack_t, None, cin_next, mask=fx[k], res=res)
-        dx = K.nhwc_stem_bwd(g, plan["w0"][ctx.ci])
+                res = K.nhwc_l1_grad(fx[k], fy[k], up, True, split=sp) if k in plan["taps"] else None
+                g = K.conv3x3_nhwc(g, pack_t, None, cin_next, mask=fx[k], res=res, split=sp)
+        dx = K.nhwc_stem_bwd(g, plan["w0"][ctx.ci], split=sp)
         ctx.fx = ctx.fy = None
-        return dx, None, None
+        return dx, None, None, None
 
 
 class TVLoss(nn.Module):

@@ -277,21 +277,23 @@ int gd_adamw(float* p, const float* g, float* m, float* v, long n, int step, flo
  *                          tie rule) and optionally gates by x > 0
  *   gd_nhwc_l1           : out (+)= mean |a - b| (losses.py:72), ws >= 1024 floats
  *   gd_nhwc_l1_grad      : g = (*upstream) / n * sign(a - b), optionally gated by a > 0
+ *   split / split_c      : operand mode "x3": the pixel-major tensors hold 3 C bf16 per pixel, [hi | lo | hi] of the C fp32
+ *                          values (see gd_disc_stem_fwd below); split_c = C (0 = plain), n = the LOGICAL element count
  * ---------------------------------------------------------------------------------------- */
 int gd_conv3x3_nhwc_pack(const float* w, int Cout, int Cin, int transposed, void* ws, size_t ws_bytes, void* stream);
 int gd_conv3x3_nhwc(const void* x, const void* wpack, const float* bias, const void* mask, const void* res, void* y, int B,
-                    int H, int W, int K, int M, int relu, void* stream);
+                    int H, int W, int K, int M, int relu, int split, void* stream);
 /* the same kernel with an fp32 NCHW result (B, M, H, W), batch stride y_bs elements: wide 3x3 convs of the generator on a
  * pixel-major bf16 copy of their input (gd_pack_16 transposed output, K = its leading dimension, zero padded) */
 int gd_conv3x3_nhwc_f32out(const void* x, const void* wpack, const float* bias, float* y32, long y_bs, int B, int H, int W, int K,
                            int M, int relu, void* stream);
 int gd_nhwc_stem_fwd(const float* img, int B, int Ci, int H, int W, const float* w, const float* bias, int Co, int relu,
-                     void* y, void* stream);
-int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, void* stream);
-int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, void* stream);
-int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx, void* stream);
-int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, void* stream);
-int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, void* stream);
+                     void* y, int split, void* stream);
+int gd_nhwc_stem_bwd(const void* g, int B, int Ci, int H, int W, const float* w, int Co, float* dimg, int split, void* stream);
+int gd_nhwc_maxpool2_fwd(const void* x, int B, int H, int W, int C, void* y, int split, void* stream);
+int gd_nhwc_maxpool2_bwd(const void* x, const void* dy, int B, int H, int W, int C, int relu_mask, void* dx, int split, void* stream);
+int gd_nhwc_l1(const void* a, const void* b, long n, float* out, int accumulate, float* ws, int split_c, void* stream);
+int gd_nhwc_l1_grad(const void* a, const void* b, long n, const float* upstream, int relu_mask, void* g, int split_c, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminator1 (discriminator.py:57-77: 4 x (conv3x3 stride 2 + LeakyReLU(0.2)) -> flatten -> fc1 -> fc2) on

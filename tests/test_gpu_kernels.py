@@ -603,6 +603,57 @@ def test_disc_trunk_kernels_on_split_activations_vs_fp64(gd, shape):
 
 
 @pytest.mark.parametrize("ci", [1, 3])
+def test_nhwc_vgg_kernels_on_split_activations(gd, ci):
+    """operand mode "x3" of the pixel-major VGG path: stem, 3x3 conv (+bias+ReLU; data-gradient form with mask and res),
+    2x2 max-pool forward / backward and the L1 distance / gradient on [hi | lo | hi] tensors (split = 1), against fp64 on
+    the unrounded values"""
+    _, K = _ops()
+    B, H, W, Co = 2, 24, 40, 64
+    img = seeded((B, ci, H, W), 271)
+    w0 = seeded((Co, ci, 3, 3), 272, 0.3)
+    b0 = seeded((Co,), 273, 0.1)
+    a = K.nhwc_stem_fwd(img.to(DEV), w0.to(DEV), b0.to(DEV), True, split=True)
+    ar = F.relu(F.conv2d(img, w0, b0, padding=1))
+    assert a.shape == (B, H, W, 3 * Co)
+    assert_close(_nchw_split(a), ar, 1e-5, "split stem fwd")
+    g = seeded((B, Co, H, W), 274)
+    dimg = K.nhwc_stem_bwd(_nhwc_split(g), w0.to(DEV), split=True)
+    assert_close(dimg, torch.nn.grad.conv2d_input((B, ci, H, W), w0, g, padding=1), 1e-4, "split stem bwd")
+    # conv + bias + ReLU, then its data-gradient form: [mask > 0] * convT(dy) + res
+    M = 48
+    w1 = seeded((M, Co, 3, 3), 275, 1.0 / math.sqrt(9 * Co))
+    b1 = seeded((M,), 276, 0.1)
+    x = seeded((B, Co, H, W), 277)
+    y = K.conv3x3_nhwc(_nhwc_split(x), K.conv3x3_nhwc_pack(K.split3_weights(w1.to(DEV), 1), False), b1.to(DEV), M, relu=True,
+                       split=True)
+    yr = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)).float()
+    assert_close(_nchw_split(y), yr, 1e-4, "split nhwc conv")
+    dy, act, res = seeded((B, M, H, W), 278), seeded((B, Co, H, W), 279), seeded((B, Co, H, W), 280)
+    dx = K.conv3x3_nhwc(_nhwc_split(dy), K.conv3x3_nhwc_pack(K.split3_weights(w1.to(DEV), 0), True), None, Co,
+                        mask=_nhwc_split(act), res=_nhwc_split(res), split=True)
+    dxr = (torch.nn.grad.conv2d_input((B, Co, H, W), w1.double(), dy.double(), padding=1) * (act > 0).double() + res.double()).float()
+    assert_close(_nchw_split(dx), dxr, 1e-4, "split nhwc data gradient with mask + res")
+    # pooling: the maximum of split values splits back into the same (hi, lo); backward exact incl. the ReLU gate
+    xv = x.clone().requires_grad_(True)
+    p = K.nhwc_maxpool2_fwd(_nhwc_split(x), split=True)
+    pr = F.max_pool2d(xv, 2)
+    assert_close(_nchw_split(p), pr.detach(), 2.0 ** -16, "split pool fwd")
+    gp = seeded(tuple(pr.shape), 281)
+    pr.backward(gp)
+    dpx = K.nhwc_maxpool2_bwd(_nhwc_split(x), _nhwc_split(gp), True, split=True)
+    assert_close(_nchw_split(dpx), xv.grad * (x > 0).float(), 2.0 ** -16, "split pool bwd")
+    fa, fb = seeded((B, Co, H, W), 282), seeded((B, Co, H, W), 283)
+    out = torch.zeros(1, device=DEV)
+    K.nhwc_l1(_nhwc_split(fa), _nhwc_split(fb), out, False, split=True)
+    K.nhwc_l1(_nhwc_split(fa), _nhwc_split(fb), out, True, split=True)
+    assert_close(out, 2 * (fa - fb).abs().mean().view(1), 1e-5, "split l1 (accumulated twice)")
+    up = torch.tensor([0.7], device=DEV)
+    gl = K.nhwc_l1_grad(_nhwc_split(fa), _nhwc_split(fb), up, True, split=True)
+    glr = 0.7 / fa.numel() * torch.sign(fa - fb) * (fa > 0).float()
+    assert_close(_nchw_split(gl), glr, 1e-5, "split l1 grad")
+
+
+@pytest.mark.parametrize("ci", [1, 3])
 def test_nhwc_stem_pool_l1(gd, ci):
     _, K = _ops()
     B, H, W, Co = 2, 24, 40, 64

@@ -719,6 +719,42 @@ def test_perceptual_loss_bf16_nhwc_path_vs_oracle(gd, ci, hw):
     assert_close(ag.grad, ar.grad, 0.2, "perceptual grad (bf16 nhwc)", rell2)
 
 
+@pytest.mark.parametrize("ci,hw", [(1, (32, 32)), (3, (40, 24)), (1, (64, 96))])
+def test_perceptual_loss_mixed_split_nhwc_path_vs_oracle(gd, ci, hw):
+    """mixed mode: the same one-node pixel-major VGG path on SPLIT activations ([hi | lo | hi], three bf16 MFMAs per
+    product; stem in fp32 FMAs) against the CPU restatement at the fp32 mode's tolerances -- value 1e-4, gradient 6e-3
+    (the bf16 node above: 2e-3 / 0.2).  Parity UNPINNED by the reference as above."""
+    from gan_danet_amd import PerceptualLoss
+    from gan_danet_amd import losses as GL
+    from oracle import modules as OM
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        po = OM.PerceptualLoss(pretrained=False)
+        pg = PerceptualLoss(pretrained=False, device=DEV)
+    torch.manual_seed(4)
+    for mod in po.vgg:
+        if isinstance(mod, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(mod.weight)
+            torch.nn.init.normal_(mod.bias, std=0.05)
+    pg.vgg.load_state_dict(po.vgg.state_dict())
+    a, b = seeded((2, ci) + hw, 93), seeded((2, ci) + hw, 94)
+    ar = a.clone().requires_grad_(True)
+    lo = po(ar, b)
+    (3.0 * lo).backward()
+    ag = a.to(DEV).requires_grad_(True)
+    with gd.precision("mixed"):
+        lg = pg(ag, b.to(DEV))
+        assert isinstance(lg.grad_fn, GL._PerceptualNhwcFn._backward_cls)
+        (3.0 * lg).backward()
+        # the plan cache follows the mode: the bf16 operators are rebuilt when the mode changes back
+        with gd.precision("bf16"):
+            lb = pg(a.to(DEV), b.to(DEV))
+    assert_close(lg, lo, 1e-4, "perceptual value (split nhwc)")
+    assert_close(ag.grad, ar.grad, 6e-3, "perceptual grad (split nhwc)", rell2)
+    assert_close(lb, lo, 2e-3, "perceptual value (bf16 nhwc after the mode change)")
+
+
 @pytest.mark.parametrize("c,hw", [(184, 16), (176, 24), (64, 32)])
 def test_pam_fused_other_widths_vs_oracle(gd, c, hw):
     """the widths the generator really uses (176/184 -> Cp = 192: channel-split dK/dV kernel; N not a multiple
