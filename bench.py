@@ -349,9 +349,10 @@ def main():
             "config": {"workload": workload, "survey_config": cfg,
                        "per_gpu_batch": B, "global_batch": B * world, "tile": T, "parallelism": f"dp{world}",
                        "storage": {"fp32": "fp32 everywhere (exact f32 MFMA)",
-                                   "mixed": "fp32 activations/weights; fused PAM on IEEE fp16 operands; 3x3 convs (generator, VGG) on "
-                                            "split-bf16 operands (hi*hi + lo*hi + hi*lo, ~2^-16); 1x1 convs / CAM / stem / "
-                                            "discriminator on the exact f32 MFMA; fp32 accumulate everywhere"}.get(
+                                   "mixed": "fp32 activations/weights in the generator, split-bf16 pixel-major activations in the "
+                                            "discriminator trunk and VGG; fused PAM on IEEE fp16 operands; every other conv / GEMM on "
+                                            "split-bf16 operands (hi*hi + lo*hi + hi*lo, ~2^-16); generator stem, nn.Linear, CAM Gram on "
+                                            "the exact f32 MFMA; fp32 accumulate everywhere"}.get(
                            args.precision, "fp32 activations/weights, 16-bit MFMA operands (" + args.precision +
                            "; generator stem conv exact), fp32 accumulate")},
             **extra, "finite": finite,
