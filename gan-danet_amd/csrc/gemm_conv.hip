@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
         }
     };
     auto store_tile = [&]() {
+        if constexpr (X3) {
         unsigned short* ap = As + am * LDA + akg * KPT_A;
         if constexpr (KPT_A >= 8) {
 #pragma unroll
@@ -394,6 +395,34 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
                 }
                 *reinterpret_cast<uint2*>(xp) = whi;
             }
+        } else {     // the plain instantiation keeps round 2's statement order (its unrolled codegen is 18 % faster)
+        unsigned short* ap = As + am * LDA + akg * KPT_A;
+        if constexpr (KPT_A >= 8) {
+#pragma unroll
+            for (int i = 0; i < KPT_A; i += 8) {
+                uint4 w;
+                w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
+                w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
+                w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
+                w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
+                *reinterpret_cast<uint4*>(ap + i) = w;
+            }
+        } else {
+            uint2 w;
+            w.x = gd_pack_bf2(ra[0], ra[1]);
+            w.y = gd_pack_bf2(ra[2], ra[3]);
+            *reinterpret_cast<uint2*>(ap) = w;
+        }
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint2 w;
+                w.x = gd_pack_bf2(rx[sb][i].x, rx[sb][i].y);
+                w.y = gd_pack_bf2(rx[sb][i].z, rx[sb][i].w);
+                *reinterpret_cast<uint2*>(Xs + sb * (BK * XLD) + (xr0 + 8 * i) * XLD + xq * 4) = w;
+            }
+        }
     };
     // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
@@ -402,6 +431,7 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
                                                     __builtin_bit_cast(gd::bf16x8_native_t, bb), c, 0, 0, 0);
     };
     auto compute_tile = [&]() {
+        if constexpr (X3) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8_t fa[PL][TM];
@@ -434,6 +464,34 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
                         mma(acc[sb][i][j], fa[0][i], fb[0][j]);
                     }
             }
+        }
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8_t fa[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                bf16x8_t fb[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned short* p = Xs + sb * (BK * XLD) + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                    fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[sb][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
+                            acc[sb][i][j], 0, 0, 0);
+            }
+        }
         }
     };
 
@@ -476,6 +534,182 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
                 const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
                 if (m >= d.M) continue;
                 float v = acc[sb][i][j][e] * alpha + rsv[e];
+                if (d.bias) v += d.bias[m];
+                if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
+                reinterpret_cast<float*>(d.y)[(long)b * d.y_bs + (long)m * HW + pn] = v + oldv[e];
+            }
+        }
+}
+
+// The plain (bf16, one 128-pixel sub-tile) form as round 2 wrote it: the generalised kernel above (NS sub-tiles, split-bf16
+// images) compiles its NS = 1 / X3 = false instantiation to a loop that measures 18 % slower on every 1x1 shape of the bench
+// (1.37 against 1.15 ms at 184 -> 184, 256 x 256, B = 32: profiles/r03_bench_kernel_stats.txt), so the default path keeps
+// this one and the template serves GD_CONV1X1_NS > 1 and GD_PREC_X3.
+template <int BM>
+__global__ __launch_bounds__(256) void conv1x1_tr_plain_kernel(const gd_conv_desc d) {
+    constexpr int LDA = BK + 8;
+    constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
+    constexpr int TM = gd::TileGeom<BM>::TM;
+    constexpr int TN = gd::TileGeom<BM>::TN;
+    constexpr int KPT_A = BM / 8;
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[BK * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int HW = d.Ho * d.Wo;
+
+    const int am = tid % BM, akg = tid / BM;
+    const bool a_row_ok = (m0 + am) < d.M;
+    const float* a_row = d.a + (long)b * d.a_bs + (long)(m0 + am) * d.a_sm;
+
+    // X loader: thread -> (channel row xr = tid>>3 .. +0, pixel quad xq = tid&7 .. +8*i): 32 rows x 32 quads
+    const int xq = tid & 31, xr0 = tid >> 5;          // 8 threads rows apart: rows xr0 + 8*i, quad xq
+    const float* x_img = d.x + (long)b * d.x_bs;
+    const int pq = n0 + xq * 4;                        // first pixel of this thread's quad
+    const bool q_full = pq + 3 < HW;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[KPT_A];
+    float4 rx[4];
+    const int T = (d.Ck + BK - 1) / BK;
+    auto load_tile = [&](int t) {
+        const int c0 = t * BK;
+#pragma unroll
+        for (int i = 0; i < KPT_A; ++i) {
+            const int c = c0 + akg * KPT_A + i;
+            ra[i] = (a_row_ok && c < d.Ck) ? a_row[(long)c * d.a_sc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + xr0 + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d.Ck) {
+                const float* p = x_img + (long)c * HW + pq;
+                if (q_full) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (pq + 0 < HW) v.x = p[0];
+                    if (pq + 1 < HW) v.y = p[1];
+                    if (pq + 2 < HW) v.z = p[2];
+                }
+                if (d.in_scale) {
+                    const float sc = d.in_scale[c], sh = d.in_shift[c];
+                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                    if (d.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (!q_full) {   // padding pixels stay zero
+                        if (pq + 0 >= HW) v.x = 0.f;
+                        if (pq + 1 >= HW) v.y = 0.f;
+                        if (pq + 2 >= HW) v.z = 0.f;
+                        v.w = 0.f;
+                    }
+                }
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+        unsigned short* ap = As + am * LDA + akg * KPT_A;
+        if constexpr (KPT_A >= 8) {
+#pragma unroll
+            for (int i = 0; i < KPT_A; i += 8) {
+                uint4 w;
+                w.x = gd_pack_bf2(ra[i + 0], ra[i + 1]);
+                w.y = gd_pack_bf2(ra[i + 2], ra[i + 3]);
+                w.z = gd_pack_bf2(ra[i + 4], ra[i + 5]);
+                w.w = gd_pack_bf2(ra[i + 6], ra[i + 7]);
+                *reinterpret_cast<uint4*>(ap + i) = w;
+            }
+        } else {
+            uint2 w;
+            w.x = gd_pack_bf2(ra[0], ra[1]);
+            w.y = gd_pack_bf2(ra[2], ra[3]);
+            *reinterpret_cast<uint2*>(ap) = w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 w;
+            w.x = gd_pack_bf2(rx[i].x, rx[i].y);
+            w.y = gd_pack_bf2(rx[i].z, rx[i].w);
+            *reinterpret_cast<uint2*>(Xs + (xr0 + 8 * i) * XLD + xq * 4) = w;
+        }
+    };
+    // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned short* p = Xs + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                fb[j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(gd::bf16x8_native_t, fa[i]), __builtin_bit_cast(gd::bf16x8_native_t, fb[j]),
+                        acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) load_tile(t + 1);
+        compute_tile();
+        __syncthreads();
+        if (t + 1 < T) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    const float alpha = d.alpha ? *d.alpha : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pn = n0 + wn * TN * 32 + j * 32 + r;
+            if (pn >= HW) continue;
+            // residual / accumulate operands: all loads before the first store (see conv3x3_halo_kernel's epilogue)
+            float rsv[16], oldv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                rsv[e] = (d.res && m < d.M) ? d.res[(long)b * d.res_bs + (long)m * HW + pn] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                oldv[e] = (d.accumulate && m < d.M) ? reinterpret_cast<const float*>(d.y)[(long)b * d.y_bs + (long)m * HW + pn] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + gd::acc_row(e, h);
+                if (m >= d.M) continue;
+                float v = acc[i][j][e] * alpha + rsv[e];
                 if (d.bias) v += d.bias[m];
                 if (d.act == GD_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (d.act == GD_ACT_LEAKY02) v = v >= 0.f ? v : 0.2f * v;
@@ -548,6 +782,10 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
             if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_kernel<32, 1, true>), grid, dim3(256), 0, s, d);
             else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_kernel<64, 1, true>), grid, dim3(256), 0, s, d);
             else hipLaunchKernelGGL((conv1x1_tr_kernel<128, 1, true>), grid, dim3(256), 0, s, d);
+        } else if (ns == 1) {
+            if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<32>), grid, dim3(256), 0, s, d);
+            else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<64>), grid, dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((conv1x1_tr_plain_kernel<128>), grid, dim3(256), 0, s, d);
         } else
         if (bm == 32) { if (ns == 4) GD_C1X1(32, 4); else if (ns == 2) GD_C1X1(32, 2); else GD_C1X1(32, 1); }
         else if (bm == 64) { if (ns == 4) GD_C1X1(64, 4); else if (ns == 2) GD_C1X1(64, 2); else GD_C1X1(64, 1); }
