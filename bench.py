@@ -354,7 +354,7 @@ def main():
                                             "split-bf16 operands (hi*hi + lo*hi + hi*lo, ~2^-16); generator stem, nn.Linear, CAM Gram on "
                                             "the exact f32 MFMA; fp32 accumulate everywhere"}.get(
                            args.precision, "fp32 activations/weights, 16-bit MFMA operands (" + args.precision +
-                           "; generator stem conv exact), fp32 accumulate")},
+                           "; generator stem conv exact, 1x1-shaped products on split-bf16 operands), fp32 accumulate")},
             **extra, "finite": finite,
             "g_out_rel_err": g_out_rel_err(gd, dev, args.precision),
             "roofline": roof,

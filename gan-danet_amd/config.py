@@ -13,12 +13,15 @@ LAYER_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "pam"
 # packs, everything else through the generic conv / GEMM kernels, which split their fp32 operands while staging them
 # (GD_PREC_X3); the stem (and nn.Linear, HBM-bound) stays on the exact f32 MFMA
 X3_CLASSES = ("dense3x3", "fuse3x3", "conv1x1", "decoder", "cam_apply", "disc", "vgg", "other")
+# classes that run split-bf16 even in the 16-bit modes because it costs (almost) nothing there
+FREE_X3_CLASSES = ("conv1x1", "cam_apply")
 
 
 @dataclass
 class _Config:
     # MFMA operand type of the GEMM-shaped kernels:
-    #   "bf16"  v_mfma_f32_32x32x16_bf16 everywhere, fused flash PAM (the fastest mode);
+    #   "bf16"  v_mfma_f32_32x32x16_bf16 everywhere, fused flash PAM (the fastest mode); the HBM-bound 1x1-shaped products
+    #           use split-bf16 operands (three bf16 MFMAs per product: still free), the stem conv the exact f32 MFMA;
     #   "fp16"  BASELINE config 5: the fused PAM kernels take IEEE fp16 operands (v_mfma_f32_32x32x16_f16), every other
     #           kernel runs as in "bf16";
     #   "fp32"  exact v_mfma_f32_32x32x2_f32 everywhere, PAM as the reference's unfused product chain (materialised
@@ -99,7 +102,10 @@ def operand_mode(layer: str) -> str:
         # takes the 16-bit modes' output error from 2.5e-2 to 1.5e-2 (profiles/r03_parity_attribution.json)
         return "exact"
     if config.precision in ("bf16", "fp16"):
-        return "16"
+        # the 1x1-shaped products (projections, transitions, skip convs, CAM apply) are HBM-bound: the 1x1 kernel splits its
+        # fp32 operands into hi + lo bf16 while staging them for +4 % of its time (1.20 against 1.16 ms at 184 -> 184), which
+        # takes their share out of the 16-bit modes' output error (1.5e-2 -> 1.2e-2 on the reference fixture)
+        return "x3" if layer in FREE_X3_CLASSES else "16"
     if config.precision == "mixed" and layer in X3_CLASSES:
         return "x3"
     return "exact"

@@ -546,15 +546,16 @@ __global__ __launch_bounds__(256) void conv1x1_tr_kernel(const gd_conv_desc d) {
 // images) compiles its NS = 1 / X3 = false instantiation to a loop that measures 18 % slower on every 1x1 shape of the bench
 // (1.37 against 1.15 ms at 184 -> 184, 256 x 256, B = 32: profiles/r03_bench_kernel_stats.txt), so the default path keeps
 // this one and the template serves GD_CONV1X1_NS > 1 and GD_PREC_X3.
-template <int BM>
+template <int BM, bool X3 = false>
 __global__ __launch_bounds__(256) void conv1x1_tr_plain_kernel(const gd_conv_desc d) {
     constexpr int LDA = BK + 8;
+    constexpr int A_PL = BM * LDA, X_PL = BK * XLD;      // X3: a second (lo) LDS image behind each tile
     constexpr int WAVES_N = gd::TileGeom<BM>::WAVES_N;
     constexpr int TM = gd::TileGeom<BM>::TM;
     constexpr int TN = gd::TileGeom<BM>::TN;
     constexpr int KPT_A = BM / 8;
-    __shared__ __attribute__((aligned(16))) unsigned short As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[BK * XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short As[(X3 ? 2 : 1) * BM * LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[(X3 ? 2 : 1) * BK * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -622,6 +623,25 @@ __global__ __launch_bounds__(256) void conv1x1_tr_plain_kernel(const gd_conv_des
     };
     auto store_tile = [&]() {
         unsigned short* ap = As + am * LDA + akg * KPT_A;
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < KPT_A; i += 4) {
+                uint2 whi, wlo;
+                gd_split_bf2(ra[i + 0], ra[i + 1], whi.x, wlo.x);
+                gd_split_bf2(ra[i + 2], ra[i + 3], whi.y, wlo.y);
+                *reinterpret_cast<uint2*>(ap + i) = whi;
+                *reinterpret_cast<uint2*>(ap + A_PL + i) = wlo;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint2 whi, wlo;
+                gd_split_bf2(rx[i].x, rx[i].y, whi.x, wlo.x);
+                gd_split_bf2(rx[i].z, rx[i].w, whi.y, wlo.y);
+                *reinterpret_cast<uint2*>(Xs + (xr0 + 8 * i) * XLD + xq * 4) = whi;
+                *reinterpret_cast<uint2*>(Xs + X_PL + (xr0 + 8 * i) * XLD + xq * 4) = wlo;
+            }
+            return;
+        }
         if constexpr (KPT_A >= 8) {
 #pragma unroll
             for (int i = 0; i < KPT_A; i += 8) {
@@ -649,6 +669,38 @@ __global__ __launch_bounds__(256) void conv1x1_tr_plain_kernel(const gd_conv_des
     // transpose-read roles: 16-lane group = 4 (k) x 16 (n) block; lane 4q+p supplies row q, columns 4p..4p+3
     const int li = lane & 15, tq = li >> 2, tp = li & 3, tg = (lane >> 4) & 1;
     auto compute_tile = [&]() {
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8_t fa[2][TM], fb[2][TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[pl][i] = *reinterpret_cast<const bf16x8_t*>(As + pl * A_PL + (wm * TM * 32 + i * 32 + r) * LDA + ks * 16 + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned short* p = Xs + pl * X_PL + (ks * 16 + 8 * h + tq) * XLD + (wn * TN + j) * 32 + 16 * tg + 4 * tp;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(p + 4 * XLD));
+                        fb[pl][j] = bf16x8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gd::bf16x8_native_t, fa[1][i]),
+                                                                           __builtin_bit_cast(gd::bf16x8_native_t, fb[0][j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gd::bf16x8_native_t, fa[0][i]),
+                                                                           __builtin_bit_cast(gd::bf16x8_native_t, fb[1][j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gd::bf16x8_native_t, fa[0][i]),
+                                                                           __builtin_bit_cast(gd::bf16x8_native_t, fb[0][j]), acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8_t fa[TM], fb[TN];
@@ -779,9 +831,9 @@ extern "C" int gd_conv2d(const gd_conv_desc* dp, void* stream) {
         dim3 grid(gd_cdiv(HWl, BN * ns), gd_cdiv(d.M, bm), d.B);
 #define GD_C1X1(BM_, NS_) hipLaunchKernelGGL((conv1x1_tr_kernel<BM_, NS_>), grid, dim3(256), 0, s, d)
         if (d.precision == GD_PREC_X3) {
-            if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_kernel<32, 1, true>), grid, dim3(256), 0, s, d);
-            else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_kernel<64, 1, true>), grid, dim3(256), 0, s, d);
-            else hipLaunchKernelGGL((conv1x1_tr_kernel<128, 1, true>), grid, dim3(256), 0, s, d);
+            if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<32, true>), grid, dim3(256), 0, s, d);
+            else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<64, true>), grid, dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((conv1x1_tr_plain_kernel<128, true>), grid, dim3(256), 0, s, d);
         } else if (ns == 1) {
             if (bm == 32) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<32>), grid, dim3(256), 0, s, d);
             else if (bm == 64) hipLaunchKernelGGL((conv1x1_tr_plain_kernel<64>), grid, dim3(256), 0, s, d);

@@ -145,8 +145,8 @@ def test_operand_modes_per_layer_class():
     try:
         cfg.config.override.clear()
         table = {
-            "bf16": {"pam": "16", "dense3x3": "16", "conv1x1": "16", "vgg": "16", "disc": "16", "stem": "exact"},
-            "fp16": {"pam": "16", "dense3x3": "16", "stem": "exact"},
+            "bf16": {"pam": "16", "dense3x3": "16", "conv1x1": "x3", "cam_apply": "x3", "vgg": "16", "disc": "16", "stem": "exact"},
+            "fp16": {"pam": "16", "dense3x3": "16", "conv1x1": "x3", "stem": "exact"},
             "fp32": {"pam": "exact", "dense3x3": "exact", "vgg": "exact", "stem": "exact"},
             "mixed": {"pam": "16", "dense3x3": "x3", "fuse3x3": "x3", "decoder": "x3", "vgg": "x3", "conv1x1": "x3",
                       "cam_apply": "x3", "disc": "x3", "stem": "exact", "other": "x3"},
