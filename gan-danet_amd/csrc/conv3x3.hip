@@ -272,11 +272,14 @@ struct NhwcConvArgs {
     int H, W, Ho, Wo, K, M, act, tiles_x, nchunks;   // act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
     float slope;
     int osplit;                   // 1: y holds 3 M channels per pixel, the result split as [hi | lo | hi] (operand mode "x3")
+    int epi_lds;                  // 1: 16-bit pixel-major output through the LDS-transposed epilogue (16-byte stores)
 };
 
 // S = stride (1: VGG stack; 2: the down-sampling convs of Discriminator1, discriminator.py:60-63 -- the patch of a
 // 4 x 32 output tile is then 9 x 65 input pixels and consecutive output pixels read patch pixels two apart)
-template <int BM, int S>
+// EPI = 1: the LDS-transposed 16-bit pixel-major epilogue (its own instantiation, so that the fp32 NCHW / direct form keeps
+// its registers)
+template <int BM, int S, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs a) {
     constexpr int TH = S == 1 ? 8 : 4;
     constexpr int WAVES_M = 2, WAVES_N = 2;
@@ -392,6 +395,89 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const NhwcConvArgs
             __syncthreads();
         }
         if (chunk + 1 < a.nchunks) store_patch();       // published by the next chunk's first barrier
+    }
+
+    // ---- pixel-major 16-bit output: every 32 x 32 accumulator tile goes through a per-wave LDS scratch (the patch image is
+    // dead behind the loop's last barrier) and leaves as 16-byte stores, four lanes covering the 64 contiguous bytes of a
+    // pixel's 32 channels -- the direct form below writes 8 bytes per lane 2 M (6 M) bytes apart.  GD_NHWC_EPI_LDS=0 (host)
+    // selects the direct form for A/B.
+    if constexpr (EPI == 1) {
+        constexpr int SLD = LD;                              // 80-byte scratch rows: 16-byte aligned reads
+        static_assert(4 * 2 * 32 * SLD <= NPIX * LD, "per-wave scratch must fit in the patch image");
+        unsigned short* scr = patch + wave * (2 * 32 * SLD);
+        const int RS = a.osplit ? 3 * a.M : a.M;
+        const int ox = x0 + r;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int oy = y0 + wn * TN + j;
+            if (oy >= a.Ho) continue;                            // wave-uniform
+            const long prow = ((long)b * a.Ho + oy) * a.Wo;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mbase = mt * BM + wm * TM * 32 + i * 32;
+                if (mbase >= a.M) continue;                      // wave-uniform
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = mbase + 8 * g + 4 * h;
+                    const bool ok = ox < a.Wo && m < a.M;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[i][j][4 * g + k];
+                        if (a.bias && ok) v[k] += a.bias[m + k];
+                        if (a.act == 1) v[k] = fmaxf(v[k], 0.f);
+                        else if (a.act == 2) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
+                    }
+                    if (ok) {
+                        const long pbase = (prow + ox) * RS;
+                        if (a.mask) {
+                            const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + pbase + m);
+                            if (!((mk.x & 0x7FFFu) && !(mk.x & 0x8000u))) v[0] = 0.f;
+                            if (!((mk.x >> 16) & 0x7FFFu) || (mk.x >> 31)) v[1] = 0.f;
+                            if (!((mk.y & 0x7FFFu) && !(mk.y & 0x8000u))) v[2] = 0.f;
+                            if (!((mk.y >> 16) & 0x7FFFu) || (mk.y >> 31)) v[3] = 0.f;
+                        }
+                        if (a.res) {
+#pragma unroll
+                            for (int part = 0; part < 2; ++part) {
+                                if (part && !a.osplit) break;
+                                const uint2 rr = *reinterpret_cast<const uint2*>(a.res + pbase + part * a.M + m);
+                                v[0] += gd_bf2f((unsigned short)(rr.x & 0xFFFFu));
+                                v[1] += gd_bf2f((unsigned short)(rr.x >> 16));
+                                v[2] += gd_bf2f((unsigned short)(rr.y & 0xFFFFu));
+                                v[3] += gd_bf2f((unsigned short)(rr.y >> 16));
+                            }
+                        }
+                    }
+                    uint2 hi, lo = make_uint2(0u, 0u);
+                    if (a.osplit) {
+                        gd_split_bf2(v[0], v[1], hi.x, lo.x);
+                        gd_split_bf2(v[2], v[3], hi.y, lo.y);
+                        *reinterpret_cast<uint2*>(scr + 32 * SLD + r * SLD + 8 * g + 4 * h) = lo;
+                    } else {
+                        hi.x = gd_pack_bf2(v[0], v[1]);
+                        hi.y = gd_pack_bf2(v[2], v[3]);
+                    }
+                    *reinterpret_cast<uint2*>(scr + r * SLD + 8 * g + 4 * h) = hi;
+                }
+                // the wave's own LDS writes above are ordered before these reads (one wave: in-order DS queue)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int px = pass * 16 + (lane >> 2), c8 = (lane & 3) * 8;
+                    const int oxp = x0 + px, m = mbase + c8;
+                    if (oxp < a.Wo && m < a.M) {
+                        unsigned short* dst = a.y + (prow + oxp) * RS + m;
+                        const u32x4_t vh = *reinterpret_cast<const u32x4_t*>(scr + px * SLD + c8);
+                        *reinterpret_cast<u32x4_t*>(dst) = vh;
+                        if (a.osplit) {
+                            *reinterpret_cast<u32x4_t*>(dst + a.M) = *reinterpret_cast<const u32x4_t*>(scr + 32 * SLD + px * SLD + c8);
+                            *reinterpret_cast<u32x4_t*>(dst + 2 * a.M) = vh;
+                        }
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: lane = pixel, accumulator registers 4g..4g+3 = four consecutive output channels (8-byte stores) ----
@@ -653,7 +739,8 @@ static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias,
                             void* y, int B, int H, int W, int K, int M, int stride, int act, float slope, void* stream,
                             float* y32 = nullptr, long y32_bs = 0, int osplit = 0) {
     NhwcConvArgs a;
-    a.y32 = y32; a.y32_bs = y32_bs; a.osplit = osplit;
+    static const int epi_env = getenv("GD_NHWC_EPI_LDS") ? atoi(getenv("GD_NHWC_EPI_LDS")) : 1;
+    a.y32 = y32; a.y32_bs = y32_bs; a.osplit = osplit; a.epi_lds = epi_env;
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wpack; a.bias = bias;
     a.mask = (const unsigned short*)mask; a.res = (const unsigned short*)res; a.y = (unsigned short*)y;
     a.H = H; a.W = W; a.K = K; a.M = M; a.act = act; a.slope = slope;
@@ -666,7 +753,15 @@ static int nhwc_conv_launch(const void* x, const void* wpack, const float* bias,
     const int tiles_y = (a.Ho + th - 1) / th;
     dim3 grid(a.tiles_x * tiles_y, mtiles, B);
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 1) {
+    if (!a.y32 && a.epi_lds) {
+        if (stride == 1) {
+            if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64, 1, 1>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 1, 1>), grid, dim3(256), 0, s, a);
+        } else {
+            if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64, 2, 1>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 2, 1>), grid, dim3(256), 0, s, a);
+        }
+    } else if (stride == 1) {
         if (bm == 64) hipLaunchKernelGGL((conv3x3_nhwc_kernel<64, 1>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_nhwc_kernel<128, 1>), grid, dim3(256), 0, s, a);
     } else {
