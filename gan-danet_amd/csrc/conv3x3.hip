@@ -873,7 +873,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
 //   dY tile is staged once for 32 NW input channels, no wave multiplies an all-zero m-tile, and the workgroup has
 //   NW x 64 threads to keep loads in flight (with waves = m-tiles a Cout of 24 left 128 threads per workgroup).
 template <int NW, int S, bool CS, bool PIPED = false>
-__global__ __launch_bounds__(NW * 64, (CS && PIPED) ? 1 : 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NW * 64, ((CS || S == 2) && PIPED) ? 1 : 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int BM = CS ? 32 : 32 * NW, NT = 64 * NW, NCH = CS ? NW : 1;
     constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
     __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(NW * 64, (CS && PIPED) ? 1 : 2) void conv3x3_wgrad_
 }  // namespace
 
 static const bool g_wgrad_cs_piped = getenv("GD_WGRAD_CS_PIPED") ? atoi(getenv("GD_WGRAD_CS_PIPED")) != 0 : true;   // A/B switch
+static const bool g_wgrad_s2_piped = getenv("GD_WGRAD_S2_PIPED") ? atoi(getenv("GD_WGRAD_S2_PIPED")) != 0 : true;   // A/B switch
 
 // dw (Cout, Cin, 3, 3) fp32 is overwritten (accumulate = 0) or added to.  Same input-transform contract as gd_conv2d.
 extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16, const float* x, long x_bs,
@@ -1176,6 +1177,9 @@ extern "C" int gd_conv3x3_wgrad(const float* dy, long dy_bs, const void* dy_bf16
         if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1, false>), grid, dim3(128), 0, s, a);
         else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 1, false>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_wgrad_kernel<6, 1, false>), grid, dim3(384), 0, s, a);
+    } else if (a.dy16 && a.x16 && best_nw == 4 && g_wgrad_s2_piped) {
+        // stride 2, both operands 16-bit (Discriminator1's trunk): the same software pipeline
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2, false, true>), grid, dim3(256), 0, s, a);
     } else {
         if (best_nw == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 2, false>), grid, dim3(128), 0, s, a);
         else if (best_nw == 4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 2, false>), grid, dim3(256), 0, s, a);
