@@ -872,8 +872,11 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const unsigned short* p) {
 // CS = true (Cout <= 32, the 24-channel dense layers): the waves are NW ci-CHUNKS sharing one 32-row dY tile -- the
 //   dY tile is staged once for 32 NW input channels, no wave multiplies an all-zero m-tile, and the workgroup has
 //   NW x 64 threads to keep loads in flight (with waves = m-tiles a Cout of 24 left 128 threads per workgroup).
+#ifndef GD_WGRAD_PIPED_MINW
+#define GD_WGRAD_PIPED_MINW 1
+#endif
 template <int NW, int S, bool CS, bool PIPED = false>
-__global__ __launch_bounds__(NW * 64, ((CS || S == 2) && PIPED) ? 1 : 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NW * 64, PIPED ? GD_WGRAD_PIPED_MINW : 2) void conv3x3_wgrad_kernel(const WgradArgs a) {
     constexpr int BM = CS ? 32 : 32 * NW, NT = 64 * NW, NCH = CS ? NW : 1;
     constexpr int PHk = S * (WTH - 1) + 3, PWk = S * (TW - 1) + 3, NPIXk = PHk * PWk;   // input patch of the tile
     __shared__ __attribute__((aligned(16))) unsigned short dys[BM * DYLD];
