@@ -50,11 +50,26 @@ def test_resume_matches_uninterrupted_run_and_generator_file_has_reference_keys(
     assert info == {"epoch": 1, "extra": {"note": "after epoch 1"}}
     assert tr2.opt_g.param_groups[0]["lr"] == tr.opt_g.param_groups[0]["lr"]
     out_b = tr2.step(x, tgt, 0.5)
-    assert_close(out_b.loss_d.view(1), out_a.loss_d.view(1).cpu(), 1e-5, "loss_d after resume")
-    assert_close(out_b.loss_g.view(1), out_a.loss_g.view(1).cpu(), 1e-5, "loss_g after resume")
+    # the losses of the resumed step: identical in 37 of 40 runs of tools/resume_noise_probe.py, 4.7e-7 / 3.6e-5 apart in the
+    # others (the split-K Gram of CAM sums with fp32 atomics; a last-bit difference in the generated image can flip a bf16
+    # rounding in the discriminator's pixel-major trunk) -- asserted at 1e-3
+    assert_close(out_b.loss_d.view(1), out_a.loss_d.view(1).cpu(), 1e-3, "loss_d after resume")
+    assert_close(out_b.loss_g.view(1), out_a.loss_g.view(1).cpu(), 1e-3, "loss_g after resume")
+    # Not bit-for-bit here (test_resume_is_bit_exact_in_deterministic_mode is): the order of the fp32 atomics varies between
+    # launches, and AdamW divides by sqrt(v).  Gradients that are analytically ZERO -- PAM's key bias (a constant added to
+    # every key shifts each softmax row by a constant), every conv bias in front of a BatchNorm -- are pure summation noise,
+    # their normalised update a coin flip of size lr.  tools/resume_noise_probe.py over 40 runs: three in four bit-identical
+    # to 1e-8, the others in a handful of discrete outcomes with up to 47 of 143 tensors beyond round-off, the weight tensors
+    # within 1.7e-4, no element further than 1.8 lr; 40 of 40 identical in deterministic mode (no race behind it).
+    # Asserted: every element within one sign-flipped AdamW step (|update| <= 1.06 lr at step 2 with betas (0.5, 0.999)),
+    # every weight tensor within 1e-3.
+    lr_g = tr.opt_g.param_groups[0]["lr"]
     for k, v in G2.state_dict().items():
         if v.dtype.is_floating_point:
-            assert_close(v, wa[k].cpu(), 1e-5, k, rell2)
+            d = (v.cpu() - wa[k].cpu()).abs().max().item()
+            assert d <= 2.2 * lr_g + 1e-7, f"{k}: |resumed - uninterrupted| = {d:.3e} > a sign-flipped AdamW step (lr {lr_g:.1e})"
+            if v.dim() >= 2:
+                assert_close(v, wa[k].cpu(), 1e-3, k, rell2)
         else:
             assert torch.equal(v, wa[k]), k
 
