@@ -68,6 +68,22 @@ __global__ void copy_slab_kernel(const float* __restrict__ src, long s_bs, float
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long)gridDim.x * blockDim.x)
         d[i] = accumulate ? d[i] + s[i] : s[i];
 }
+// 16 bytes per lane (the scalar form above moved 1.6 TB/s on the 1 GB slab copies of the dense blocks): chw, both batch strides
+// multiples of 4 floats and both bases 16-byte aligned (checked by the host)
+__global__ __launch_bounds__(256) void copy_slab_vec_kernel(const float4* __restrict__ src, long s_bs4, float4* __restrict__ dst,
+                                                           long d_bs4, long n4, int accumulate) {
+    const int b = blockIdx.y;
+    const float4* s = src + (long)b * s_bs4;
+    float4* d = dst + (long)b * d_bs4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = s[i];
+        if (accumulate) {
+            const float4 o = d[i];
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        d[i] = v;
+    }
+}
 
 // ---- row softmax ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int cols,
@@ -789,7 +805,11 @@ extern "C" int gd_copy_rows(const float* src, long s_bs, long s_ld, float* dst, 
 extern "C" int gd_copy_slab(const float* src, long s_bs, float* dst, long d_bs, int B, long chw, int accumulate,
                             void* stream) {
     GD_CHECK_ARG(src && dst && B > 0 && B <= 65535 && chw > 0, "gd_copy_slab: bad arguments");
-    hipLaunchKernelGGL(copy_slab_kernel, dim3(grid_for(chw), B), dim3(256), 0, GD_S, src, s_bs, dst, d_bs, chw, accumulate);
+    if (chw % 4 == 0 && s_bs % 4 == 0 && d_bs % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0)
+        hipLaunchKernelGGL(copy_slab_vec_kernel, dim3(grid_for(chw / 4), B), dim3(256), 0, GD_S, (const float4*)src, s_bs / 4,
+                           (float4*)dst, d_bs / 4, chw / 4, accumulate);
+    else
+        hipLaunchKernelGGL(copy_slab_kernel, dim3(grid_for(chw), B), dim3(256), 0, GD_S, src, s_bs, dst, d_bs, chw, accumulate);
     GD_LAUNCH_CHECK();
     return 0;
 }

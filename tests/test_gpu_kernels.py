@@ -687,6 +687,22 @@ def test_nhwc_stem_pool_l1(gd, ci):
     assert_close(_nchw(gl), ref, 1e-2, "l1 grad")
 
 
+def test_copy_slab_vector_and_scalar_paths(gd):
+    """gd_copy_slab: channel slices of wider slabs in and out, plain and accumulating; 16-byte path (aligned, multiples of 4)
+    and the scalar path (odd sizes / a slice starting at an odd channel of an odd-sized plane)"""
+    _, K = _ops()
+    for (B, Ctot, C, H, W, c0) in ((3, 12, 8, 8, 8, 4), (2, 7, 5, 5, 7, 1), (2, 9, 4, 6, 6, 3)):
+        src = seeded((B, Ctot, H, W), 401).to(DEV)
+        dst = seeded((B, Ctot + 3, H, W), 402).to(DEV)
+        ref = dst.clone()
+        K.copy_slab(src[:, c0:c0 + C], dst[:, 1:1 + C])
+        ref[:, 1:1 + C] = src[:, c0:c0 + C]
+        assert torch.equal(dst, ref)
+        K.copy_slab(src[:, :C], dst[:, 2:2 + C], accumulate=True)
+        ref[:, 2:2 + C] += src[:, :C]
+        assert torch.equal(dst, ref)
+
+
 def test_shift_sum9_is_the_one_hot_3x3_conv(gd):
     """ShiftSum9Fn (last step of the collapsed generator tail): bias + sum_tap shift(u_tap) equals conv3x3(u, E), E the
     one-hot (1, 9, 3, 3) kernel with E[0][tap][tap // 3][tap % 3] = 1; forward and both gradients, exact up to the order
